@@ -1,0 +1,80 @@
+"""ctypes binding of ``libhivt_mi355.so`` (the C ABI declared in ``include/hivt_mi355.h``).
+
+The library is built in-tree by ``hivt_gan_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no CPU fallback: if the shared library is missing the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhivt_mi355.so")
+
+_P = c_void_p  # every device pointer crosses as void*
+
+# name -> (restype, argtypes); order and meaning follow include/hivt_mi355.h
+SIGNATURES = {
+    "hivt_version": (c_int, []),
+    "hivt_last_error": (c_char_p, []),
+    "hivt_edges_workspace_bytes": (c_size_t, [c_int64]),
+    "hivt_edges_temporal": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32,
+                                    c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hivt_edges_radius": (c_int, [_P, c_int64, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hivt_csr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hivt_csr_build": (c_int, [_P, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
+    "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P]),
+    "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "hivt_seg_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32, c_int32,
+                                  c_float, c_uint64, _P, _P, _P, c_int, _P]),
+    "hivt_seg_attn_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64,
+                                  c_int32, c_int32, c_float, c_uint64, _P, _P, _P, c_int64, c_int, _P]),
+    "hivt_segment_sum_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
+    "hivt_gated_update_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P]),
+    "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,
+                                      _P, _P, c_int64, _P, c_int64, _P]),
+    "hivt_laplace_workspace_bytes": (c_size_t, [c_int32]),
+    "hivt_laplace_minmode_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P,
+                                         _P, c_size_t, _P]),
+    "hivt_laplace_minmode_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,
+                                         _P, _P, _P]),
+}
+
+_lib = None
+
+
+class HivtLibraryError(RuntimeError):
+    """A C-ABI call returned a non-zero code; the message is ``hivt_last_error()``."""
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once and declare every prototype."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HivtLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an ``int``-returning entry point and raise on a non-zero return code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.hivt_last_error().decode("utf-8", "replace")
+        raise HivtLibraryError(f"{name} failed with code {rc}: {msg}")
+
+
+def query(name: str, *args) -> int:
+    """Invoke a size query (``*_workspace_bytes``) or ``hivt_version``."""
+    return int(getattr(load(), name)(*args))

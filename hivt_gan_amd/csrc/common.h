@@ -1,0 +1,78 @@
+// Shared helpers for the gfx950 (CDNA4, wave64) kernels of libhivt_mi355.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/hivt_mi355.h"
+
+namespace hivt {
+
+constexpr int kWave = 64;
+
+// ---- error reporting ------------------------------------------------------------------------
+// One message per host thread; forward runs on the Python thread and backward on the autograd
+// worker thread, so the text must not be shared between threads.
+void set_error(const char* fmt, ...);
+
+#define HIVT_REQUIRE(cond, code, ...)          \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::hivt::set_error(__VA_ARGS__);          \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+#define HIVT_CHECK_LAUNCH(what)                                                         \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      ::hivt::set_error("%s: launch failed: %s", (what), hipGetErrorString(e__));       \
+      return HIVT_ERR_LAUNCH;                                                           \
+    }                                                                                   \
+  } while (0)
+
+#define HIVT_CHECK_HIP(expr, what)                                                      \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      ::hivt::set_error("%s: %s", (what), hipGetErrorString(e__));                      \
+      return HIVT_ERR_LAUNCH;                                                           \
+    }                                                                                   \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum over the aligned group of GROUP consecutive lanes (GROUP a power of two <= 64).
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Counter-based uniform in [0,1): one 64-bit mix (splitmix64 finaliser) of (seed, index).
+// Forward and backward evaluate it at the same (seed, index) and so agree on the mask.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t index) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (index + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace hivt

@@ -1,0 +1,353 @@
+// Edge construction for the HiVT edge-attention path: order-preserving edge filters (validity
+// sub-graph + radius), stable CSR build, and the atomics-free segment sum of rows.
+//
+// All of these are integer / byte work bound by HBM and launch latency; nothing here is shaped
+// into a GEMM.  The filters are a three-launch stream compaction (count per 1024-item tile, one
+// single-block scan of the tile counts, ordered write) so the output keeps the input order, which
+// fixes the CSR order and therefore the floating-point accumulation order downstream.
+#include "common.h"
+
+namespace hivt {
+namespace {
+
+constexpr int kFilterThreads = 256;
+constexpr int kFilterItemsPerThread = 4;
+constexpr int kFilterTile = kFilterThreads * kFilterItemsPerThread;
+
+struct EdgeRec {
+  int32_t src, dst;
+  float ax, ay;
+};
+
+// Predicate for per-timestep agent-agent edges (models/local_encoder.py:58-61 + utils.py:69-78).
+struct TemporalPred {
+  const int64_t* edge_index;
+  int64_t E0;
+  const uint8_t* pm;
+  int64_t pm_stride;
+  const float* pos;
+  int64_t pos_sn, pos_st;
+  int32_t N, t0;
+  float radius;
+
+  __device__ __forceinline__ bool operator()(int64_t item, EdgeRec& r) const {
+    const int32_t tt = (int32_t)(item / E0);
+    const int64_t e = item - (int64_t)tt * E0;
+    const int32_t t = t0 + tt;
+    const int64_t s = edge_index[e];
+    const int64_t d = edge_index[E0 + e];
+    if (pm[s * pm_stride + t] | pm[d * pm_stride + t]) return false;
+    const float2 ps = *reinterpret_cast<const float2*>(pos + s * pos_sn + (int64_t)t * pos_st);
+    const float2 pd = *reinterpret_cast<const float2*>(pos + d * pos_sn + (int64_t)t * pos_st);
+    r.ax = ps.x - pd.x;
+    r.ay = ps.y - pd.y;
+    r.src = (int32_t)s + tt * N;
+    r.dst = (int32_t)d + tt * N;
+    if (radius > 0.0f) {
+      // same rounding as the host framework's 2-norm over a pair: sqrt(fma(y, y, fl(x*x)))
+      const float d2 = __fmaf_rn(r.ay, r.ay, __fmul_rn(r.ax, r.ax));
+      return __fsqrt_rn(d2) < radius;
+    }
+    return true;
+  }
+};
+
+// Predicate for a given edge list with given attributes (utils.py:69-78 at local_encoder.py:80).
+struct RadiusPred {
+  const int64_t* edge_index;
+  int64_t E0;
+  const float* attr;
+  float radius;
+
+  __device__ __forceinline__ bool operator()(int64_t item, EdgeRec& r) const {
+    const float2 a = *reinterpret_cast<const float2*>(attr + 2 * item);
+    r.ax = a.x;
+    r.ay = a.y;
+    r.src = (int32_t)edge_index[item];
+    r.dst = (int32_t)edge_index[E0 + item];
+    if (radius > 0.0f) {
+      const float d2 = __fmaf_rn(a.y, a.y, __fmul_rn(a.x, a.x));
+      return __fsqrt_rn(d2) < radius;
+    }
+    return true;
+  }
+};
+
+template <class Pred>
+__global__ __launch_bounds__(kFilterThreads) void filter_count_kernel(Pred pred, int64_t items,
+                                                                      int32_t* __restrict__ tile_counts) {
+  __shared__ int wave_tot[kFilterThreads / kWave];
+  const int64_t base = (int64_t)blockIdx.x * kFilterTile;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kFilterItemsPerThread; ++j) {
+    const int64_t item = base + j * kFilterThreads + threadIdx.x;
+    EdgeRec r;
+    if (item < items && pred(item, r)) ++cnt;
+  }
+  cnt = wave_sum_i(cnt);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < kFilterThreads / kWave; ++w) s += wave_tot[w];
+    tile_counts[blockIdx.x] = s;
+  }
+}
+
+// Exclusive scan of `n` int32 values by ONE block; also writes the grand total.
+__global__ __launch_bounds__(1024) void scan_single_block_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                 int32_t* __restrict__ out,
+                                                                 int32_t* __restrict__ total_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  int s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += in[i];
+  part[tid] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid == 0 ? 0 : part[tid - 1];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == 1023 && total_out != nullptr) *total_out = part[1023];
+}
+
+template <class Pred>
+__global__ __launch_bounds__(kFilterThreads) void filter_write_kernel(Pred pred, int64_t items,
+                                                                      const int32_t* __restrict__ tile_offsets,
+                                                                      int32_t* __restrict__ src_out,
+                                                                      int32_t* __restrict__ dst_out,
+                                                                      float* __restrict__ attr_out) {
+  __shared__ int wave_tot[kFilterThreads / kWave];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kFilterTile;
+  int running = tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kFilterItemsPerThread; ++j) {
+    const int64_t item = base + j * kFilterThreads + threadIdx.x;
+    EdgeRec r;
+    const bool keep = item < items && pred(item, r);
+    const unsigned long long ballot = __ballot(keep);
+    const int lane_prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kFilterThreads / kWave; ++w) {
+      const int c = wave_tot[w];
+      if (w < wave) wave_off += c;
+      total += c;
+    }
+    if (keep) {
+      const int64_t p = (int64_t)running + wave_off + lane_prefix;
+      src_out[p] = r.src;
+      dst_out[p] = r.dst;
+      *reinterpret_cast<float2*>(attr_out + 2 * p) = make_float2(r.ax, r.ay);
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+template <class Pred>
+int run_filter(const Pred& pred, int64_t items, int32_t* src_out, int32_t* dst_out, float* attr_out,
+               int32_t* count_out, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+  if (items == 0) {
+    HIVT_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t), stream), what);
+    return HIVT_OK;
+  }
+  const int64_t tiles = (items + kFilterTile - 1) / kFilterTile;
+  HIVT_REQUIRE(ws != nullptr && ws_bytes >= hivt_edges_workspace_bytes(items), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small (%zu < %zu)", what, ws_bytes, hivt_edges_workspace_bytes(items));
+  int32_t* tile_counts = reinterpret_cast<int32_t*>(ws);
+  int32_t* tile_offsets = tile_counts + align_up(tiles, 64);
+  hipLaunchKernelGGL(filter_count_kernel<Pred>, dim3((unsigned)tiles), dim3(kFilterThreads), 0, stream, pred, items,
+                     tile_counts);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, tile_counts, tiles, tile_offsets,
+                     count_out);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(filter_write_kernel<Pred>, dim3((unsigned)tiles), dim3(kFilterThreads), 0, stream, pred, items,
+                     tile_offsets, src_out, dst_out, attr_out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+// ---- CSR build ------------------------------------------------------------------------------
+__global__ void csr_hist_kernel(const int32_t* __restrict__ key, int64_t E, int32_t* __restrict__ deg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) atomicAdd(&deg[key[i]], 1);
+}
+
+// Unordered placement: slot = rowptr[key] + arrival ticket.  The order inside a row is fixed
+// afterwards by csr_row_sort_kernel, so the result does not depend on atomic arrival order.
+__global__ void csr_place_kernel(const int32_t* __restrict__ key, int64_t E, const int32_t* __restrict__ rowptr,
+                                 int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) {
+    const int32_t k = key[i];
+    const int32_t slot = rowptr[k] + atomicAdd(&cursor[k], 1);
+    tmp[slot] = (int32_t)i;
+  }
+}
+
+// One wave per row: rank every edge id among the ids of its row (ids are distinct) and write it to
+// its rank, giving ascending original positions = the stable order.
+__global__ __launch_bounds__(256) void csr_row_sort_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ tmp, int32_t num_rows,
+                                                           int32_t* __restrict__ perm) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= num_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  const int len = end - beg;
+  if (len <= kWave) {
+    const int mine = lane < len ? tmp[beg + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < len; ++j) rank += (__shfl(mine, j, 64) < mine) ? 1 : 0;
+    if (lane < len) perm[beg + rank] = mine;
+  } else {
+    for (int i = lane; i < len; i += kWave) {
+      const int mine = tmp[beg + i];
+      int rank = 0;
+      for (int j = 0; j < len; ++j) rank += (tmp[beg + j] < mine) ? 1 : 0;
+      perm[beg + rank] = mine;
+    }
+  }
+}
+
+// ---- segment sum of rows --------------------------------------------------------------------
+// One wave per output row; lanes cover the row in float4 columns, several input rows in flight.
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ rows, int64_t row_stride,
+                                                               int32_t width, const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ perm, int32_t num_rows,
+                                                               float* __restrict__ out, int64_t out_stride) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= num_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = rowptr[row], end = rowptr[row + 1];
+  for (int c = lane * 4; c < width; c += kWave * 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = beg; i < end; ++i) {
+      const int64_t r = perm ? perm[i] : i;
+      const float4 v = *reinterpret_cast<const float4*>(rows + r * row_stride + c);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)row * out_stride + c) = acc;
+  }
+}
+
+}  // namespace
+}  // namespace hivt
+
+using namespace hivt;
+
+extern "C" size_t hivt_edges_workspace_bytes(int64_t items) {
+  const int64_t tiles = (items + kFilterTile - 1) / kFilterTile;
+  return align_up((size_t)(2 * align_up((size_t)(tiles > 0 ? tiles : 1), 64)) * sizeof(int32_t), 256);
+}
+
+extern "C" int hivt_edges_temporal(const int64_t* edge_index, int64_t E0, const uint8_t* padding_mask,
+                                   int64_t pm_stride, const float* positions, int64_t pos_stride_n,
+                                   int64_t pos_stride_t, int32_t N, int32_t t0, int32_t T, float radius,
+                                   int32_t* src_out, int32_t* dst_out, float* attr_out, int32_t* count_out,
+                                   void* workspace, size_t workspace_bytes, hivt_stream_t stream) {
+  const char* what = "hivt_edges_temporal";
+  HIVT_REQUIRE(E0 >= 0 && N >= 0 && T >= 0 && t0 >= 0, HIVT_ERR_ARG, "%s: negative size", what);
+  HIVT_REQUIRE(count_out != nullptr, HIVT_ERR_ARG, "%s: count_out is null", what);
+  const int64_t items = E0 * (int64_t)T;
+  HIVT_REQUIRE(items < (int64_t)1 << 31 && (int64_t)N * T < (int64_t)1 << 31, HIVT_ERR_ARG,
+               "%s: %lld candidate edges / %lld nodes exceed int32 indexing", what, (long long)items,
+               (long long)N * T);
+  HIVT_REQUIRE(items == 0 || (edge_index && padding_mask && positions && src_out && dst_out && attr_out),
+               HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(pos_stride_t % 2 == 0 && pos_stride_n % 2 == 0, HIVT_ERR_ARG,
+               "%s: position strides must be even (8-byte aligned pairs)", what);
+  TemporalPred pred{edge_index, E0, padding_mask, pm_stride, positions, pos_stride_n, pos_stride_t, N, t0, radius};
+  return run_filter(pred, items, src_out, dst_out, attr_out, count_out, workspace, workspace_bytes,
+                    (hipStream_t)stream, what);
+}
+
+extern "C" int hivt_edges_radius(const int64_t* edge_index, int64_t E0, const float* edge_attr, float radius,
+                                 int32_t* src_out, int32_t* dst_out, float* attr_out, int32_t* count_out,
+                                 void* workspace, size_t workspace_bytes, hivt_stream_t stream) {
+  const char* what = "hivt_edges_radius";
+  HIVT_REQUIRE(E0 >= 0 && E0 < (int64_t)1 << 31, HIVT_ERR_ARG, "%s: bad edge count %lld", what, (long long)E0);
+  HIVT_REQUIRE(count_out != nullptr, HIVT_ERR_ARG, "%s: count_out is null", what);
+  HIVT_REQUIRE(E0 == 0 || (edge_index && edge_attr && src_out && dst_out && attr_out), HIVT_ERR_ARG,
+               "%s: null pointer", what);
+  RadiusPred pred{edge_index, E0, edge_attr, radius};
+  return run_filter(pred, E0, src_out, dst_out, attr_out, count_out, workspace, workspace_bytes,
+                    (hipStream_t)stream, what);
+}
+
+extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {
+  // cursor[num_rows] + tmp[E]
+  return align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256) +
+         align_up((size_t)(E > 0 ? E : 1) * sizeof(int32_t), 256);
+}
+
+extern "C" int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, int32_t* rowptr, int32_t* perm,
+                              void* workspace, size_t workspace_bytes, hivt_stream_t stream_) {
+  const char* what = "hivt_csr_build";
+  hipStream_t stream = (hipStream_t)stream_;
+  HIVT_REQUIRE(E >= 0 && E < (int64_t)1 << 31 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(rowptr != nullptr, HIVT_ERR_ARG, "%s: rowptr is null", what);
+  HIVT_REQUIRE(E == 0 || (key && perm), HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace != nullptr && workspace_bytes >= hivt_csr_workspace_bytes(E, num_rows), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small (%zu < %zu)", what, workspace_bytes, hivt_csr_workspace_bytes(E, num_rows));
+  int32_t* cursor = reinterpret_cast<int32_t*>(workspace);
+  int32_t* tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) +
+                                            align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256));
+  // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
+  HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), stream), what);
+  if (E > 0) {
+    hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, cursor);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, cursor, (int64_t)num_rows, rowptr,
+                     rowptr + num_rows);
+  HIVT_CHECK_LAUNCH(what);
+  if (E > 0) {
+    HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)num_rows * sizeof(int32_t), stream), what);
+    hipLaunchKernelGGL(csr_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, rowptr,
+                       cursor, tmp);
+    HIVT_CHECK_LAUNCH(what);
+    hipLaunchKernelGGL(csr_row_sort_kernel, dim3((unsigned)((num_rows + 3) / 4)), dim3(256), 0, stream, rowptr, tmp,
+                       num_rows, perm);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  return HIVT_OK;
+}
+
+extern "C" int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
+                                     const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
+                                     hivt_stream_t stream) {
+  const char* what = "hivt_segment_sum_rows";
+  HIVT_REQUIRE(width > 0 && width % 4 == 0 && row_stride % 4 == 0 && out_stride % 4 == 0, HIVT_ERR_ARG,
+               "%s: width and strides must be multiples of 4 floats", what);
+  HIVT_REQUIRE(num_rows >= 0, HIVT_ERR_ARG, "%s: negative row count", what);
+  if (num_rows == 0) return HIVT_OK;
+  HIVT_REQUIRE(rows && rowptr && out, HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((unsigned)((num_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     rows, row_stride, width, rowptr, perm, num_rows, out, out_stride);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}

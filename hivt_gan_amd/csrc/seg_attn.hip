@@ -1,0 +1,403 @@
+// Kernels (b)+(c): per-edge QK dot, segment softmax over CSR rows and weighted sum of V, and the
+// matching backward.  Both are single-pass streaming kernels bound by HBM bandwidth: forward reads
+// each K and V row once; backward reads K, V once and writes dK, dV once.
+//
+// Mapping (wave64): a K/V row of D floats is covered by LPR = D/4 lanes holding one float4 each,
+// so one wave instruction loads EPI = 64/LPR edges (2 at D=128, 4 at D=64) as full 512-byte /
+// 256-byte contiguous rows.  A head spans LPH = D/(4H) adjacent lanes; the QK dot is finished with
+// log2(LPH) xor-shuffles.  Each lane slot runs an online softmax over its share of the row's edges
+// (4 edges in flight per slot), slots are merged with xor-shuffles, and for long rows the 4 waves
+// of a block split one row and merge through LDS.  No atomics: every target row is owned by one
+// wave or one block, so results are deterministic.
+#include "common.h"
+
+#include <math.h>
+
+namespace hivt {
+namespace {
+
+constexpr float kNegSentinel = -1.0e30f;  // "no edge seen yet"; exp(kNegSentinel - x) == 0
+constexpr int kUnroll = 4;
+
+struct SegAttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  int64_t kv_stride;
+  const float* k_node;
+  const float* v_node;
+  int64_t node_stride;
+  const int32_t* src;
+  const int32_t* rowptr;
+  int32_t N;
+  int32_t H;
+  float scale_inv;
+  float dropout_p;
+  uint64_t seed;
+  // forward outputs / backward saved
+  float* out;
+  float* m;
+  float* den;
+  // backward only
+  const float* d_out;
+  float* dq;
+  float* dk;
+  float* dv;
+  int64_t dkv_stride;
+};
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& v) {
+  acc.x += s * v.x;
+  acc.y += s * v.y;
+  acc.z += s * v.z;
+  acc.w += s * v.w;
+}
+__device__ __forceinline__ void scale4(float4& a, float s) {
+  a.x *= s;
+  a.y *= s;
+  a.z *= s;
+  a.w *= s;
+}
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 shfl_xor4(const float4& a, int o) {
+  return make_float4(__shfl_xor(a.x, o, 64), __shfl_xor(a.y, o, 64), __shfl_xor(a.z, o, 64), __shfl_xor(a.w, o, 64));
+}
+
+// Merge two online-softmax states (m, l, acc) <- (m, l, acc) (+) (m2, l2, acc2).
+__device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, float m2, float l2, const float4& acc2) {
+  const float mn = fmaxf(m, m2);
+  const float c1 = expf(m - mn), c2 = expf(m2 - mn);
+  l = l * c1 + l2 * c2;
+  acc.x = acc.x * c1 + acc2.x * c2;
+  acc.y = acc.y * c1 + acc2.y * c2;
+  acc.z = acc.z * c1 + acc2.z * c2;
+  acc.w = acc.w * c1 + acc2.w * c2;
+  m = mn;
+}
+
+template <int D, int LPH, int WPN, bool GLOBAL>
+__global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int EPI = kWave / LPR;
+  constexpr int NPB = 4 / WPN;  // target rows per 256-thread block
+  __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * NPB + wave / WPN;
+  const int win = wave % WPN;
+  if (n >= a.N) return;  // block-uniform when WPN == 4
+  const int sub = lane / LPR;
+  const int c = lane % LPR;
+  const int h = c / LPH;
+
+  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+  float4 qs = ldg4(a.q + (int64_t)n * D + 4 * c);
+  scale4(qs, a.scale_inv);
+  const bool drop = a.dropout_p > 0.0f;
+  const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+
+  float m = kNegSentinel, l = 0.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  constexpr int STRIDE = WPN * EPI;
+  for (int e0 = beg + win * EPI + sub; e0 < end; e0 += STRIDE * kUnroll) {
+    float4 kk[kUnroll], vv[kUnroll];
+    float s[kUnroll];
+    bool ok[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int e = e0 + u * STRIDE;
+      ok[u] = e < end;
+      const int64_t ee = ok[u] ? e : e0;
+      kk[u] = ldg4(a.k + ee * a.kv_stride + 4 * c);
+      vv[u] = ldg4(a.v + ee * a.kv_stride + 4 * c);
+      if (GLOBAL) {
+        const int64_t j = a.src[ee];
+        kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
+        vv[u] = add4(vv[u], ldg4(a.v_node + j * a.node_stride + 4 * c));
+      }
+    }
+    float smax = m;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float part = group_sum<LPH>(dot4(qs, kk[u]));
+      s[u] = ok[u] ? part : kNegSentinel;
+      smax = fmaxf(smax, s[u]);
+    }
+    const float corr = expf(m - smax);
+    l *= corr;
+    scale4(acc, corr);
+    m = smax;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      float p = ok[u] ? expf(s[u] - m) : 0.0f;
+      l += p;
+      if (drop) {
+        const uint64_t idx = (uint64_t)(e0 + u * STRIDE) * (uint64_t)a.H + (uint64_t)h;
+        p = uniform01(a.seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
+      }
+      fma4(acc, p, vv[u]);
+    }
+  }
+
+  // merge the EPI lane slots of this wave
+#pragma unroll
+  for (int o = LPR; o < kWave; o <<= 1) {
+    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+    const float4 acc2 = shfl_xor4(acc, o);
+    merge_state(m, l, acc, m2, l2, acc2);
+  }
+
+  if (WPN > 1) {
+    if (sub == 0) {
+      float* slot = smem + (wave * LPR + c) * 6;
+      slot[0] = m;
+      slot[1] = l;
+      slot[2] = acc.x;
+      slot[3] = acc.y;
+      slot[4] = acc.z;
+      slot[5] = acc.w;
+    }
+    __syncthreads();
+    if (win != 0) return;
+#pragma unroll
+    for (int w = 1; w < WPN; ++w) {
+      const float* slot = smem + ((wave + w) * LPR + c) * 6;
+      merge_state(m, l, acc, slot[0], slot[1], make_float4(slot[2], slot[3], slot[4], slot[5]));
+    }
+  }
+
+  if (sub == 0) {
+    const float den = l + 1e-16f;
+    const float inv = 1.0f / den;
+    *reinterpret_cast<float4*>(a.out + (int64_t)n * D + 4 * c) =
+        make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    if (c % LPH == 0) {
+      a.m[(int64_t)n * a.H + h] = m;
+      a.den[(int64_t)n * a.H + h] = den;
+    }
+  }
+}
+
+template <int D, int LPH, int WPN, bool GLOBAL>
+__global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
+  constexpr int LPR = D / 4;
+  constexpr int EPI = kWave / LPR;
+  constexpr int NPB = 4 / WPN;
+  __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * NPB + wave / WPN;
+  const int win = wave % WPN;
+  if (n >= a.N) return;
+  const int sub = lane / LPR;
+  const int c = lane % LPR;
+  const int h = c / LPH;
+
+  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+  float4 qs = ldg4(a.q + (int64_t)n * D + 4 * c);
+  scale4(qs, a.scale_inv);
+  const float4 go = ldg4(a.d_out + (int64_t)n * D + 4 * c);
+  const float4 o4 = ldg4(a.out + (int64_t)n * D + 4 * c);
+  const float delta = group_sum<LPH>(dot4(go, o4));
+  const float mh = a.m[(int64_t)n * a.H + h];
+  const float inv_den = 1.0f / a.den[(int64_t)n * a.H + h];
+  const bool drop = a.dropout_p > 0.0f;
+  const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  constexpr int STRIDE = WPN * EPI;
+  for (int e0 = beg + win * EPI + sub; e0 < end; e0 += STRIDE * kUnroll) {
+    float4 kk[kUnroll], vv[kUnroll];
+    bool ok[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int e = e0 + u * STRIDE;
+      ok[u] = e < end;
+      const int64_t ee = ok[u] ? e : e0;
+      kk[u] = ldg4(a.k + ee * a.kv_stride + 4 * c);
+      vv[u] = ldg4(a.v + ee * a.kv_stride + 4 * c);
+      if (GLOBAL) {
+        const int64_t j = a.src[ee];
+        kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
+        vv[u] = add4(vv[u], ldg4(a.v_node + j * a.node_stride + 4 * c));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float s = group_sum<LPH>(dot4(qs, kk[u]));
+      const float dav = group_sum<LPH>(dot4(go, vv[u]));
+      if (ok[u]) {
+        const int64_t e = e0 + u * STRIDE;
+        const float alpha = expf(s - mh) * inv_den;
+        float ms = 1.0f;
+        if (drop) {
+          const uint64_t idx = (uint64_t)e * (uint64_t)a.H + (uint64_t)h;
+          ms = uniform01(a.seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
+        }
+        const float am = alpha * ms;
+        const float ds = alpha * (dav * ms - delta);
+        *reinterpret_cast<float4*>(a.dv + e * a.dkv_stride + 4 * c) =
+            make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
+        *reinterpret_cast<float4*>(a.dk + e * a.dkv_stride + 4 * c) =
+            make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+        fma4(dq, ds, kk[u]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int o = LPR; o < kWave; o <<= 1) dq = add4(dq, shfl_xor4(dq, o));
+
+  if (WPN > 1) {
+    if (sub == 0) *reinterpret_cast<float4*>(smem + (wave * LPR + c) * 4) = dq;
+    __syncthreads();
+    if (win != 0) return;
+#pragma unroll
+    for (int w = 1; w < WPN; ++w) dq = add4(dq, *reinterpret_cast<const float4*>(smem + ((wave + w) * LPR + c) * 4));
+  }
+  if (sub == 0) {
+    scale4(dq, a.scale_inv);
+    *reinterpret_cast<float4*>(a.dq + (int64_t)n * D + 4 * c) = dq;
+  }
+}
+
+template <int D, int LPH, int WPN, bool GLOBAL>
+int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
+  constexpr int NPB = 4 / WPN;
+  const unsigned grid = (unsigned)((a.N + NPB - 1) / NPB);
+  if (backward)
+    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL>), dim3(grid), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL>), dim3(grid), dim3(256), 0, stream, a);
+  return 0;
+}
+
+template <int D, int LPH>
+int launch_dl(bool backward, bool long_rows, bool global, const SegAttnArgs& a, hipStream_t stream) {
+  if constexpr (LPH <= D / 4) {
+    if (long_rows) {
+      return global ? launch_one<D, LPH, 4, true>(backward, a, stream)
+                    : launch_one<D, LPH, 4, false>(backward, a, stream);
+    }
+    return global ? launch_one<D, LPH, 1, true>(backward, a, stream)
+                  : launch_one<D, LPH, 1, false>(backward, a, stream);
+  } else {
+    return -1;
+  }
+}
+
+template <int D>
+int launch_d(int lph, bool backward, bool long_rows, bool global, const SegAttnArgs& a, hipStream_t stream) {
+  switch (lph) {
+    case 1: return launch_dl<D, 1>(backward, long_rows, global, a, stream);
+    case 2: return launch_dl<D, 2>(backward, long_rows, global, a, stream);
+    case 4: return launch_dl<D, 4>(backward, long_rows, global, a, stream);
+    case 8: return launch_dl<D, 8>(backward, long_rows, global, a, stream);
+    default: return -1;
+  }
+}
+
+int dispatch(int D, int H, bool backward, int64_t E, bool global, const SegAttnArgs& a, hipStream_t stream) {
+  const int lph = D / (4 * H);
+  // long rows: split one target row over the 4 waves of a block
+  const bool long_rows = a.N > 0 && (E / a.N) >= 48;
+  switch (D) {
+    case 16: return launch_d<16>(lph, backward, long_rows, global, a, stream);
+    case 32: return launch_d<32>(lph, backward, long_rows, global, a, stream);
+    case 64: return launch_d<64>(lph, backward, long_rows, global, a, stream);
+    case 128: return launch_d<128>(lph, backward, long_rows, global, a, stream);
+    case 256: return launch_d<256>(lph, backward, long_rows, global, a, stream);
+    default: return -1;
+  }
+}
+
+int check_shape(const char* what, int32_t N, int64_t E, int32_t D, int32_t H, int64_t kv_stride, int dtype,
+                float dropout_p) {
+  HIVT_REQUIRE(dtype == HIVT_F32, HIVT_ERR_UNSUPPORTED, "%s: only HIVT_F32 is built", what);
+  HIVT_REQUIRE(N >= 0 && E >= 0 && E < (int64_t)1 << 31, HIVT_ERR_ARG, "%s: bad sizes N=%d E=%lld", what, N,
+               (long long)E);
+  HIVT_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128 || D == 256, HIVT_ERR_ARG,
+               "%s: embed_dim %d not in {16,32,64,128,256}", what, D);
+  HIVT_REQUIRE(H > 0 && D % (4 * H) == 0, HIVT_ERR_ARG, "%s: head dim D/H must be a multiple of 4 (D=%d H=%d)", what,
+               D, H);
+  const int lph = D / (4 * H);
+  HIVT_REQUIRE(lph == 1 || lph == 2 || lph == 4 || lph == 8, HIVT_ERR_ARG,
+               "%s: head dim %d not in {4,8,16,32}", what, D / H);
+  HIVT_REQUIRE(kv_stride >= D && kv_stride % 4 == 0, HIVT_ERR_ARG, "%s: kv_stride %lld must be >= D and 16-B aligned",
+               what, (long long)kv_stride);
+  HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  return HIVT_OK;
+}
+
+}  // namespace
+}  // namespace hivt
+
+using namespace hivt;
+
+extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride,
+                                 const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
+                                 const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                                 uint64_t seed, float* out, float* m_out, float* den_out, int dtype,
+                                 hivt_stream_t stream) {
+  const char* what = "hivt_seg_attn_fwd";
+  int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
+  if (rc != HIVT_OK) return rc;
+  if (N == 0) return HIVT_OK;
+  const bool global = k_node != nullptr;
+  HIVT_REQUIRE(q && rowptr && out && m_out && den_out, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(E == 0 || (k && v), HIVT_ERR_ARG, "%s: null k/v with E > 0", what);
+  HIVT_REQUIRE(!global || (v_node && src && node_stride >= D && node_stride % 4 == 0), HIVT_ERR_ARG,
+               "%s: node terms need v_node, src and a 16-B aligned node_stride >= D", what);
+  SegAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
+  a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
+  a.rowptr = rowptr; a.N = N; a.H = H;
+  a.scale_inv = 1.0f / sqrtf((float)(D / H));
+  a.dropout_p = dropout_p; a.seed = seed;
+  a.out = out; a.m = m_out; a.den = den_out;
+  HIVT_REQUIRE(dispatch(D, H, false, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
+               "%s: no kernel for D=%d H=%d", what, D, H);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v,
+                                 int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
+                                 const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
+                                 const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                                 uint64_t seed, float* dq, float* dk, float* dv, int64_t dkv_stride, int dtype,
+                                 hivt_stream_t stream) {
+  const char* what = "hivt_seg_attn_bwd";
+  int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
+  if (rc != HIVT_OK) return rc;
+  if (N == 0) return HIVT_OK;
+  const bool global = k_node != nullptr;
+  HIVT_REQUIRE(d_out && q && rowptr && out && m && den && dq, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(E == 0 || (k && v && dk && dv), HIVT_ERR_ARG, "%s: null k/v/dk/dv with E > 0", what);
+  HIVT_REQUIRE(dkv_stride >= D && dkv_stride % 4 == 0, HIVT_ERR_ARG, "%s: dkv_stride must be >= D and 16-B aligned",
+               what);
+  HIVT_REQUIRE(!global || (v_node && src && node_stride >= D && node_stride % 4 == 0), HIVT_ERR_ARG,
+               "%s: node terms need v_node, src and a 16-B aligned node_stride >= D", what);
+  SegAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
+  a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
+  a.rowptr = rowptr; a.N = N; a.H = H;
+  a.scale_inv = 1.0f / sqrtf((float)(D / H));
+  a.dropout_p = dropout_p; a.seed = seed;
+  a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);
+  a.d_out = d_out; a.dq = dq; a.dk = dk; a.dv = dv; a.dkv_stride = dkv_stride;
+  HIVT_REQUIRE(dispatch(D, H, true, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
+               "%s: no kernel for D=%d H=%d", what, D, H);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}

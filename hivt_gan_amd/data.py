@@ -1,0 +1,281 @@
+"""PyG-free scene container, batching and a seeded nuScenes-shaped scene generator.
+
+The reference stores one scene per ``TemporalData`` (``utils.py:8-62``, a
+``torch_geometric.data.Data`` subclass) and batches scenes with
+``Batch.from_data_list`` (``datasets/nuscenes_dataset.py:116-118``).  This module
+provides the same attribute/item access and the same batching offsets without
+torch_geometric:
+
+* tensors are concatenated on dim 0, except ``edge_index`` and
+  ``lane_actor_index`` which are concatenated on dim 1 (``utils.py:42-46``);
+* ``edge_index`` is offset by the running node count, ``lane_actor_index`` by
+  ``[[lanes so far], [nodes so far]]`` (``utils.py:48-62``);
+* ``agent_index`` / ``av_index`` become global node ids (PyG offsets every key
+  containing "index" by ``num_nodes``), 0-d ``theta`` becomes ``[B]``,
+  ``origin[1,2]`` becomes ``[B,2]``, strings become lists.
+
+The generator follows the tensor shapes, dtypes and edge orders produced by the
+reference's offline preprocessor (``nuscenes_dataset.py:101-173,217-245,284-323``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+_DIM1_KEYS = ("edge_index", "lane_actor_index")
+
+
+class TemporalData:
+    """Attribute- and item-addressable bag of tensors describing one scene or a batch."""
+
+    def __init__(self, **fields) -> None:
+        object.__setattr__(self, "_store", {})
+        for k, v in fields.items():
+            self._store[k] = v
+
+    # -- mapping / attribute protocol (mirrors torch_geometric.data.Data) --------------
+    def __getitem__(self, key: str):
+        return self._store[key]
+
+    def __setitem__(self, key: str, value) -> None:
+        self._store[key] = value
+
+    def __contains__(self, key: str) -> bool:
+        return key in self._store
+
+    def __getattr__(self, key: str):
+        store = object.__getattribute__(self, "_store")
+        if key in store:
+            return store[key]
+        raise AttributeError(key)
+
+    def __setattr__(self, key: str, value) -> None:
+        self._store[key] = value
+
+    def keys(self) -> Iterable[str]:
+        return self._store.keys()
+
+    def get(self, key: str, default=None):
+        return self._store.get(key, default)
+
+    @property
+    def num_graphs(self) -> int:
+        return int(self._store.get("_num_graphs", 1))
+
+    def to(self, device, non_blocking: bool = False) -> "TemporalData":
+        out = TemporalData()
+        for k, v in self._store.items():
+            out._store[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
+        return out
+
+    def clone(self) -> "TemporalData":
+        out = TemporalData()
+        for k, v in self._store.items():
+            out._store[k] = v.clone() if torch.is_tensor(v) else v
+        return out
+
+    def __repr__(self) -> str:
+        parts = []
+        for k, v in self._store.items():
+            parts.append(f"{k}={list(v.shape)}" if torch.is_tensor(v) else f"{k}={v!r}")
+        return "TemporalData(" + ", ".join(parts) + ")"
+
+
+def collate(scenes: List[TemporalData]) -> TemporalData:
+    """Batch scenes with the offsets of ``Batch.from_data_list`` for this data class."""
+    if len(scenes) == 0:
+        raise ValueError("cannot collate an empty list of scenes")
+    out: Dict[str, object] = {}
+    node_off, lane_off = 0, 0
+    node_offs, lane_offs = [], []
+    for s in scenes:
+        node_offs.append(node_off)
+        lane_offs.append(lane_off)
+        node_off += int(s.num_nodes)
+        lane_off += int(s.lane_vectors.shape[0]) if "lane_vectors" in s else 0
+    keys = list(scenes[0].keys())
+    for k in keys:
+        vals = [s[k] for s in scenes]
+        v0 = vals[0]
+        if k == "num_nodes":
+            out[k] = node_off
+        elif k == "edge_index":
+            out[k] = torch.cat([v + o for v, o in zip(vals, node_offs)], dim=1)
+        elif k == "lane_actor_index":
+            out[k] = torch.cat(
+                [v + torch.tensor([[lo], [no]], dtype=v.dtype) for v, lo, no in zip(vals, lane_offs, node_offs)],
+                dim=1)
+        elif k in ("agent_index", "av_index"):
+            out[k] = torch.tensor([int(v) + o for v, o in zip(vals, node_offs)], dtype=torch.long)
+        elif torch.is_tensor(v0):
+            out[k] = torch.stack(vals) if v0.dim() == 0 else torch.cat(vals, dim=0)
+        elif isinstance(v0, (int, float)):
+            out[k] = torch.tensor(vals)
+        else:
+            out[k] = list(vals)
+    batch_vec = torch.cat([torch.full((int(s.num_nodes),), i, dtype=torch.long) for i, s in enumerate(scenes)])
+    out["batch"] = batch_vec
+    out["_num_graphs"] = len(scenes)
+    return TemporalData(**out)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic scenes
+# --------------------------------------------------------------------------------------
+def _rand_int(gen: torch.Generator, lo: int, hi: int) -> int:
+    return int(torch.randint(lo, hi + 1, (1,), generator=gen))
+
+
+def make_scene(index: int,
+               historical_steps: int = 20,
+               future_steps: int = 30,
+               local_radius: float = 50.0,
+               num_agents: Optional[int] = None,
+               num_lanes: Optional[int] = None,
+               all_valid: bool = False,
+               random_lane_attrs: bool = False,
+               base_seed: int = 2022) -> TemporalData:
+    """One synthetic scene; deterministic in ``index`` (generator seed ``base_seed + index``).
+
+    Agents are constant-velocity tracks (speed U[0,15] m/s, dt 0.5 s, heading U[0,2pi)) starting in
+    [-60,60]^2 m, each observed on one contiguous window of the 50 steps.  Lanes are ~1 m segments
+    laid along 8-16 random polylines in the same box.  Every derived tensor (padding rules, BOS mask,
+    rotate angles, displacement features, edge orders, lane-actor pre-filter) is computed by the rules
+    of the reference preprocessor (``nuscenes_dataset.py:101-173,217-245,284-323``).
+    """
+    T, Hf = historical_steps, future_steps
+    S = T + Hf
+    gen = torch.Generator().manual_seed(base_seed + index)
+    n = num_agents if num_agents is not None else _rand_int(gen, 12, 28)
+    nl = num_lanes if num_lanes is not None else _rand_int(gen, 200, 400)
+
+    start = (torch.rand(n, 2, generator=gen) * 2 - 1) * 60.0
+    speed = torch.rand(n, generator=gen) * 15.0
+    heading = torch.rand(n, generator=gen) * (2 * math.pi)
+    vel = torch.stack([speed * torch.cos(heading), speed * torch.sin(heading)], dim=-1)
+    steps = torch.arange(S, dtype=torch.float32).view(1, S, 1)
+    world = start.unsqueeze(1) + vel.unsqueeze(1) * (0.5 * steps)  # [n, S, 2]
+
+    padding_mask = torch.ones(n, S, dtype=torch.bool)
+    if all_valid:
+        padding_mask[:] = False
+    else:
+        long_track = torch.rand(n, generator=gen) < 0.7
+        for i in range(n):
+            if bool(long_track[i]):
+                first = _rand_int(gen, 0, T - 2)
+                last = _rand_int(gen, T - 1, S - 1)
+            else:
+                first = _rand_int(gen, 0, T - 1)  # must be seen at least once in the history
+                last = _rand_int(gen, first, S - 1)
+            padding_mask[i, first:last + 1] = False
+    world = torch.where(padding_mask.unsqueeze(-1), torch.zeros_like(world), world)
+
+    # scene frame: origin / heading of the actor with the longest history (nuscenes_dataset.py:103-122)
+    hist_counts = (~padding_mask[:, :T]).sum(dim=1)
+    av_index = int(torch.argmax(hist_counts))
+    hv = (~padding_mask[av_index, :T]).nonzero().squeeze(-1)
+    if hv.numel() >= 2:
+        origin = world[av_index, hv[-1]].clone()
+        hd = world[av_index, hv[-1]] - world[av_index, hv[-2]]
+        theta = torch.atan2(hd[1], hd[0])
+    else:
+        origin = world[av_index, hv[-1]].clone() if hv.numel() else torch.zeros(2)
+        theta = torch.tensor(0.0)
+    rot = torch.tensor([[math.cos(float(theta)), -math.sin(float(theta))],
+                        [math.sin(float(theta)), math.cos(float(theta))]], dtype=torch.float32)
+    pos = torch.matmul(world - origin, rot)
+
+    # no future for agents unseen at the last history step (nuscenes_dataset.py:125)
+    padding_mask[padding_mask[:, T - 1], T:] = True
+
+    # heading of each agent from its last two valid history points (nuscenes_dataset.py:217-226)
+    rotate_angles = torch.zeros(n)
+    for i in range(n):
+        idx = (~padding_mask[i, :T]).nonzero().squeeze(-1)
+        if idx.numel() >= 2:
+            v = pos[i, idx[-1]] - pos[i, idx[-2]]
+            rotate_angles[i] = torch.atan2(v[1], v[0])
+        else:
+            padding_mask[i, T:] = True
+
+    bos_mask = torch.zeros(n, T, dtype=torch.bool)
+    bos_mask[:, 0] = ~padding_mask[:, 0]
+    bos_mask[:, 1:T] = padding_mask[:, :T - 1] & ~padding_mask[:, 1:T]
+
+    # displacement features (nuscenes_dataset.py:228-245)
+    feat = pos.clone()
+    feat[:, T:] = torch.where((padding_mask[:, T - 1].unsqueeze(-1) | padding_mask[:, T:]).unsqueeze(-1),
+                              torch.zeros(n, Hf, 2), feat[:, T:] - feat[:, T - 1].unsqueeze(-2))
+    feat[:, 1:T] = torch.where((padding_mask[:, :T - 1] | padding_mask[:, 1:T]).unsqueeze(-1),
+                               torch.zeros(n, T - 1, 2), feat[:, 1:T] - feat[:, :T - 1])
+    feat[:, 0] = 0.0
+    x, y = feat[:, :T].contiguous(), feat[:, T:].contiguous()
+
+    # all ordered pairs, source-major (itertools.permutations order, nuscenes_dataset.py:139-141)
+    ar = torch.arange(n)
+    src = ar.repeat_interleave(n)
+    dst = ar.repeat(n)
+    off_diag = src != dst
+    edge_index = torch.stack([src[off_diag], dst[off_diag]]).long().contiguous()
+
+    # lanes: ~1 m segments along random polylines
+    n_poly = _rand_int(gen, 8, 16)
+    per = [nl // n_poly + (1 if j < nl % n_poly else 0) for j in range(n_poly)]
+    lane_pos, lane_vec = [], []
+    for cnt in per:
+        if cnt == 0:
+            continue
+        p0 = (torch.rand(2, generator=gen) * 2 - 1) * 60.0
+        h0 = float(torch.rand(1, generator=gen)) * 2 * math.pi
+        curv = (float(torch.rand(1, generator=gen)) - 0.5) * 0.04
+        ang = h0 + curv * torch.arange(cnt, dtype=torch.float32)
+        seg = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1) * (0.9 + 0.2 * torch.rand(cnt, 1, generator=gen))
+        pts = p0 + torch.cumsum(torch.cat([torch.zeros(1, 2), seg[:-1]]), dim=0)
+        lane_pos.append(pts)
+        lane_vec.append(seg)
+    if lane_vec:
+        lane_pos_t = torch.matmul(torch.cat(lane_pos) - origin, rot)
+        lane_vectors = torch.matmul(torch.cat(lane_vec), rot)
+    else:
+        lane_pos_t = torch.zeros(0, 2)
+        lane_vectors = torch.zeros(0, 2)
+    L = lane_vectors.shape[0]
+    if random_lane_attrs:
+        is_inter = torch.randint(0, 2, (L,), generator=gen).to(torch.uint8)
+        turn = torch.randint(0, 3, (L,), generator=gen).to(torch.uint8)
+        control = torch.randint(0, 2, (L,), generator=gen).to(torch.uint8)
+    else:  # the reference preprocessor writes zeros (nuscenes_dataset.py:284-286)
+        is_inter = torch.zeros(L, dtype=torch.uint8)
+        turn = torch.zeros(L, dtype=torch.uint8)
+        control = torch.zeros(L, dtype=torch.uint8)
+
+    # lane-major (lane, visible actor) pairs, pre-filtered by distance (nuscenes_dataset.py:304-322)
+    visible = (~padding_mask[:, T - 1]).nonzero().squeeze(-1)
+    if L > 0 and visible.numel() > 0:
+        la_lane = torch.arange(L).repeat_interleave(visible.numel())
+        la_actor = visible.repeat(L)
+        node_pos = pos[visible, T - 1]
+        la_vec = lane_pos_t.repeat_interleave(visible.numel(), 0) - node_pos.repeat(L, 1)
+        keep = torch.norm(la_vec, dim=1) < local_radius
+        lane_actor_index = torch.stack([la_lane[keep], la_actor[keep]]).long()
+        lane_actor_vectors = la_vec[keep]
+    else:
+        lane_actor_index = torch.zeros(2, 0, dtype=torch.long)
+        lane_actor_vectors = torch.zeros(0, 2)
+
+    return TemporalData(
+        x=x, positions=pos.clone(), edge_index=edge_index, y=y, num_nodes=n,
+        padding_mask=padding_mask, bos_mask=bos_mask, rotate_angles=rotate_angles,
+        lane_vectors=lane_vectors, is_intersections=is_inter, turn_directions=turn,
+        traffic_controls=control, lane_actor_index=lane_actor_index,
+        lane_actor_vectors=lane_actor_vectors, seq_id=f"synthetic-{base_seed + index}",
+        av_index=av_index, agent_index=av_index, city="synthetic",
+        origin=origin.unsqueeze(0), theta=theta)
+
+
+def make_batch(num_scenes: int, first_index: int = 0, **scene_kwargs) -> TemporalData:
+    """``num_scenes`` consecutive synthetic scenes collated into one batch (CPU tensors)."""
+    return collate([make_scene(first_index + i, **scene_kwargs) for i in range(num_scenes)])

@@ -1,0 +1,192 @@
+"""HiVT generator + multi-scale critics and the G + D + R1 training step, without Lightning.
+
+``HiVT`` keeps the constructor arguments, ``forward`` contract and state_dict keys of
+``models/hivt.py:31-169``.  ``training_step`` restates Case B of the reference
+(``models/hivt.py:287-342``): generator forward, supervised losses, critic update with hinge + R1,
+generator update with the adversarial term.  Differences, all deliberate:
+
+* ``use_gan`` is honoured.  The reference reads it from ``**kwargs`` where it can never be
+  (``models/hivt.py:52`` vs ``:76``), which silently disables the GAN branch it ships.
+* the empty-future branch of the supervised losses yields three values (the reference returns two
+  at ``models/hivt.py:178-185`` but unpacks three at ``:298``).
+* agents without any valid future step are masked out with weights instead of boolean indexing
+  (``models/hivt.py:227-231``), which gives the same losses without a data-dependent shape.
+* gradients of one backward are reduced across data-parallel ranks by a caller-supplied hook on a
+  flat buffer (the reference relies on Lightning's DDP wrapper, ``train.py:69-78``).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .critics import LongScaleCritic, MidScaleCritic, ShortScaleCritic
+from .decoder import MLPDecoder
+from .global_interactor import GlobalInteractor
+from .local_encoder import LocalEncoder
+from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss,
+                     SoftTargetCrossEntropyLoss, fused_supervised_losses)
+
+
+class HiVT(nn.Module):
+
+    def __init__(self, historical_steps: int = 20, future_steps: int = 30, num_modes: int = 6, rotate: bool = True,
+                 node_dim: int = 2, edge_dim: int = 2, embed_dim: int = 64, num_heads: int = 8, dropout: float = 0.1,
+                 num_temporal_layers: int = 4, num_global_layers: int = 3, local_radius: float = 50,
+                 parallel: bool = False, lr: float = 5e-4, weight_decay: float = 1e-4, T_max: int = 64,
+                 use_gan: bool = False, lambda_adv: float = 0.1, lambda_r1: float = 1.0, critic_steps: int = 1,
+                 short_horizon: int = 10, mid_horizon: int = 20, critic_lr: float = 1e-4, **kwargs) -> None:
+        super().__init__()
+        self.historical_steps = historical_steps
+        self.future_steps = future_steps
+        self.num_modes = num_modes
+        self.rotate = rotate
+        self.parallel = parallel
+        self.lr, self.weight_decay, self.T_max = lr, weight_decay, T_max
+        self.use_gan = bool(use_gan)
+        self.lambda_adv, self.lambda_r1 = lambda_adv, lambda_r1
+        self.critic_steps = critic_steps
+        self.short_horizon, self.mid_horizon = short_horizon, mid_horizon
+        self.critic_lr = critic_lr
+        self.check_finite = bool(kwargs.get("check_finite", True))
+
+        self.local_encoder = LocalEncoder(historical_steps=historical_steps, node_dim=node_dim, edge_dim=edge_dim,
+                                          embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,
+                                          num_temporal_layers=num_temporal_layers, local_radius=local_radius,
+                                          parallel=parallel)
+        self.global_interactor = GlobalInteractor(historical_steps=historical_steps, embed_dim=embed_dim,
+                                                  edge_dim=edge_dim, num_modes=num_modes, num_heads=num_heads,
+                                                  num_layers=num_global_layers, dropout=dropout, rotate=rotate)
+        self.decoder = MLPDecoder(local_channels=embed_dim, global_channels=embed_dim, future_steps=future_steps,
+                                  num_modes=num_modes, uncertain=True)
+        self.reg_loss = LaplaceNLLLoss(reduction="mean")
+        self.cls_loss = SoftTargetCrossEntropyLoss(reduction="mean")
+        if self.use_gan:
+            self.D_short = ShortScaleCritic(horizon=short_horizon, input_dim=2, hidden_dim=128)
+            self.D_mid = MidScaleCritic(horizon=mid_horizon, input_dim=2, hidden_dim=256)
+            self.D_long = LongScaleCritic(horizon=future_steps, input_dim=2, hidden_dim=256)
+            self.d_loss_fn = AdversarialDiscriminatorLoss(lambda_r1=lambda_r1)
+            self.g_loss_fn = AdversarialGeneratorLoss(lambda_adv=lambda_adv)
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def critics(self) -> Dict[str, nn.Module]:
+        return {"short": self.D_short, "mid": self.D_mid, "long": self.D_long}
+
+    def generator_parameters(self) -> List[nn.Parameter]:
+        """Parameter order of the generator optimizer (``models/hivt.py:439-442``)."""
+        return (list(self.local_encoder.parameters()) + list(self.global_interactor.parameters())
+                + list(self.decoder.parameters()))
+
+    def critic_parameters(self) -> List[nn.Parameter]:
+        """Parameter order of the critic optimizer (``models/hivt.py:448-451``)."""
+        return list(self.D_short.parameters()) + list(self.D_mid.parameters()) + list(self.D_long.parameters())
+
+    def configure_optimizers(self):
+        """AdamW (all generator parameters decayed, ``models/hivt.py:428,444``) with cosine annealing;
+        a second AdamW without decay for the critics (``models/hivt.py:453``)."""
+        fused = next(self.parameters()).is_cuda
+        if not self.use_gan:
+            opt = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, fused=fused)
+            return [opt], [torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=self.T_max, eta_min=0.0)]
+        opt_g = torch.optim.AdamW(self.generator_parameters(), lr=self.lr, weight_decay=self.weight_decay,
+                                  fused=fused)
+        opt_d = torch.optim.AdamW(self.critic_parameters(), lr=self.critic_lr, weight_decay=0.0, fused=fused)
+        return [opt_g, opt_d], [torch.optim.lr_scheduler.CosineAnnealingLR(opt_g, T_max=self.T_max, eta_min=0.0)]
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, data) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(y_hat [F, N, H, 4], pi [N, F]).  Like the reference, rotates ``data.y`` into each agent's
+        frame IN PLACE on the batch object and stores ``rotate_mat`` on it (``models/hivt.py:151-169``):
+        re-using one batch object for two forwards needs ``data.y`` restored in between."""
+        if self.rotate:
+            ang = data["rotate_angles"]
+            sin, cos = torch.sin(ang), torch.cos(ang)
+            rotate_mat = torch.stack([cos, -sin, sin, cos], dim=-1).view(-1, 2, 2)
+            if data.get("y") is not None:
+                data["y"] = torch.bmm(data["y"], rotate_mat)
+            data["rotate_mat"] = rotate_mat
+        else:
+            data["rotate_mat"] = None
+        local_embed = self.local_encoder(data=data)
+        global_embed = self.global_interactor(data=data, local_embed=local_embed)
+        return self.decoder(local_embed=local_embed, global_embed=global_embed)
+
+    def _supervised_losses(self, data, y_hat: torch.Tensor, pi: torch.Tensor):
+        """(reg_loss, cls_loss, best_mode), ``models/hivt.py:174-209`` on the fused kernel."""
+        return fused_supervised_losses(y_hat, pi, data["y"], data["padding_mask"], self.historical_steps)
+
+    def _real_fake(self, data, y_hat: torch.Tensor, best_mode: torch.Tensor):
+        """Real / best-mode fake futures of every agent plus the keep mask of agents with a valid
+        future (``models/hivt.py:215-231``; horizons are cut inside the critics)."""
+        n = y_hat.shape[1]
+        fake = y_hat[best_mode, torch.arange(n, device=y_hat.device), :, :2]
+        keep = (~data["padding_mask"][:, self.historical_steps:]).any(dim=1)
+        return data["y"], fake, keep
+
+    # ------------------------------------------------------------------------------------------
+    def training_step(self, data, opt_g: torch.optim.Optimizer, opt_d: Optional[torch.optim.Optimizer] = None,
+                      sync_grads: Optional[Callable[[str], None]] = None) -> Dict[str, torch.Tensor]:
+        """One optimisation step; returns detached loss tensors (no host read-back here).
+
+        ``sync_grads(group)`` is called after each backward with ``"critic"`` or ``"generator"`` and must
+        average that group's gradients across data-parallel ranks.  A rank whose batch trips a guard
+        still calls it (with zero gradients) so every rank enters the same collectives
+        (``models/hivt.py:262-265,301-310``)."""
+        def skip(reason: str) -> Dict[str, torch.Tensor]:
+            # zero-gradient participation keeps data-parallel ranks in lock-step
+            for group, opt in (("critic", opt_d), ("generator", opt_g)):
+                if opt is None or (group == "critic" and not self.use_gan):
+                    continue
+                opt.zero_grad(set_to_none=False)
+                if sync_grads is not None:
+                    sync_grads(group)
+            return {"skipped": torch.ones((), device=data["y"].device)}
+
+        if self.check_finite and bool(torch.isnan(data["y"]).any()):  # models/hivt.py:264
+            return skip("nan target")
+        y_hat, pi = self(data)
+        if self.check_finite and not bool(torch.isfinite(y_hat).all()):  # models/hivt.py:272,294
+            return skip("non-finite prediction")
+        reg_loss, cls_loss, best_mode = self._supervised_losses(data, y_hat, pi)
+        logs: Dict[str, torch.Tensor] = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
+
+        if not self.use_gan:  # Case A, models/hivt.py:270-285 (gradient clipping is the caller's business)
+            loss = reg_loss + cls_loss
+            opt_g.zero_grad(set_to_none=False)
+            loss.backward()
+            if sync_grads is not None:
+                sync_grads("generator")
+            opt_g.step()
+            logs["loss"] = loss.detach()
+            return logs
+
+        real, fake, keep = self._real_fake(data, y_hat, best_mode)
+        critic_params = self.critic_parameters()
+        for _ in range(self.critic_steps):  # models/hivt.py:305-314
+            d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
+            opt_d.zero_grad(set_to_none=False)
+            d_loss.backward()
+            if sync_grads is not None:
+                sync_grads("critic")
+            opt_d.step()
+        # generator update (models/hivt.py:317-327); critic weight gradients of this backward would be
+        # discarded by the next opt_d.zero_grad(), so they are not computed at all
+        for p in critic_params:
+            p.requires_grad_(False)
+        try:
+            g_adv, g_logs = self.g_loss_fn.forward_masked(self.critics, fake, keep)
+            g_total = reg_loss + cls_loss + g_adv
+            opt_g.zero_grad(set_to_none=False)
+            g_total.backward()
+        finally:
+            for p in critic_params:
+                p.requires_grad_(True)
+        if sync_grads is not None:
+            sync_grads("generator")
+        opt_g.step()
+        logs.update({"d_loss": d_loss.detach(), "g_adv": g_adv.detach(), "g_total": g_total.detach()})
+        logs.update(d_logs)
+        logs.update(g_logs)
+        return logs

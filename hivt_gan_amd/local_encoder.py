@@ -1,0 +1,321 @@
+"""Local encoder: agent-agent (AAEncoder) and agent-lane (ALEncoder) edge attention, the temporal
+transformer between them, and the wrapper that builds every edge set of a batch on the device.
+
+The modules keep the constructors, forward signatures and state_dict keys of
+``models/local_encoder.py`` so callers and checkpoints are interchangeable, but none of them uses
+torch_geometric: message / aggregate / update run as
+
+    edge gather+rotate kernel  ->  per-edge embedding MLP (dense)  ->  fused K|V projection
+    ->  segment-softmax attention kernel over CSR rows  ->  gated-update kernel
+
+with Q hoisted from per-edge to per-node (``lin_q(c)[dst] == lin_q(c[dst])``).  The 20 timesteps of
+the agent-agent stage always run as ONE batched call (node id ``t*N + n``), which is the arithmetic
+of the reference's ``parallel=True`` branch (``local_encoder.py:62-71,135-144,168-169``) and, row
+for row, of its per-timestep loop (``:73-78``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .embedding import MultipleInputEmbedding, SingleInputEmbedding, init_weights
+from .ops import EdgeSet
+
+
+# ----------------------------------------------------------------------------------------------
+# Edge plan: every edge set of one batch, built with one host read-back of the three edge counts
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class EdgePlan:
+    agent_agent: EdgeSet   # all timesteps, node id t*N + n        (local_encoder.py:58-61,65)
+    lane_actor: EdgeSet    # lane -> actor within the radius        (local_encoder.py:80)
+    interaction: EdgeSet   # agents valid at the last history step  (global_interactor.py:48-50)
+
+
+class DistanceDropEdge:
+    """Radius filter with the call signature of ``utils.py:64-78`` (device-side compaction)."""
+
+    def __init__(self, max_distance: Optional[float] = None) -> None:
+        self.max_distance = max_distance
+
+    def __call__(self, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.max_distance is None:
+            return edge_index, edge_attr
+        src, dst, attr, count = ops.edges_radius(edge_index, edge_attr, self.max_distance)
+        e = int(count.item())
+        return torch.stack([src[:e], dst[:e]]).long(), attr[:e]
+
+
+def subgraph(subset: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tensor, None]:
+    """Edges whose two endpoints are in the boolean ``subset`` (``torch_geometric.utils.subgraph`` as
+    called at ``local_encoder.py:59`` / ``global_interactor.py:48``), order preserving."""
+    n = subset.shape[0]
+    pm = (~subset).view(n, 1)
+    pos = torch.zeros(n, 1, 2, dtype=torch.float32, device=subset.device)
+    src, dst, _attr, count = ops.edges_temporal(edge_index, pm, pos, 0, 1, None)
+    e = int(count.item())
+    return torch.stack([src[:e], dst[:e]]).long(), None
+
+
+def build_edge_plan(data, historical_steps: int, local_radius: Optional[float]) -> EdgePlan:
+    """All three edge sets of a batch, filtered and CSR-grouped on the device."""
+    T = historical_steps
+    n = int(data.num_nodes)
+    num_lanes = int(data["lane_vectors"].shape[0])
+    aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
+    la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
+    gi = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], T - 1, 1, None)
+    counts = torch.cat([aa[3], la[3], gi[3]]).cpu()  # the only host synchronisation of the forward pass
+    e_aa, e_la, e_gi = (int(c) for c in counts)
+    plan = EdgePlan(
+        agent_agent=ops.make_edge_set(aa[0][:e_aa], aa[1][:e_aa], aa[2][:e_aa], T * n, T * n),
+        lane_actor=ops.make_edge_set(la[0][:e_la], la[1][:e_la], la[2][:e_la], num_lanes, n),
+        interaction=ops.make_edge_set(gi[0][:e_gi], gi[1][:e_gi], gi[2][:e_gi], n, n))
+    return plan
+
+
+def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
+    src = edge_index[0].to(torch.int32).contiguous()
+    dst = edge_index[1].to(torch.int32).contiguous()
+    return ops.make_edge_set(src, dst, edge_attr.contiguous(), num_src, num_dst)
+
+
+def _fused_linear(x: torch.Tensor, a: nn.Linear, b: nn.Linear) -> torch.Tensor:
+    """[a(x) | b(x)] as one GEMM."""
+    return F.linear(x, torch.cat([a.weight, b.weight], dim=0), torch.cat([a.bias, b.bias], dim=0))
+
+
+class _EdgeAttentionBase(nn.Module):
+    """Parameters and the dense tail shared by AAEncoder and ALEncoder."""
+
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float) -> None:
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.lin_q = nn.Linear(embed_dim, embed_dim)
+        self.lin_k = nn.Linear(embed_dim, embed_dim)
+        self.lin_v = nn.Linear(embed_dim, embed_dim)
+        self.lin_self = nn.Linear(embed_dim, embed_dim)
+        self.attn_drop = nn.Dropout(dropout)
+        self.lin_ih = nn.Linear(embed_dim, embed_dim)
+        self.lin_hh = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.proj_drop = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim * 4), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                                 nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
+
+    def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet) -> torch.Tensor:
+        """message (Q.K, segment softmax, weighting) + aggregate + update + out_proj for per-edge
+        embeddings already in CSR order (``local_encoder.py:174-188,197-199`` / ``:364-379,391-394``)."""
+        kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
+        q = self.lin_q(center)
+        agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training)
+        upd = ops.gated_update(agg, self.lin_ih(agg), _fused_linear(center, self.lin_hh, self.lin_self))
+        return self.proj_drop(self.out_proj(upd))
+
+    def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
+        return self.mlp(x)
+
+
+class AAEncoder(_EdgeAttentionBase):
+    """Agent-agent edge attention of one timestep or of all timesteps batched
+    (``models/local_encoder.py:87-202``)."""
+
+    def __init__(self, historical_steps: int, node_dim: int, edge_dim: int, embed_dim: int, num_heads: int = 8,
+                 dropout: float = 0.1, parallel: bool = False, **kwargs) -> None:
+        super().__init__(embed_dim, num_heads, dropout)
+        self.historical_steps = historical_steps
+        self.parallel = parallel
+        self.center_embed = SingleInputEmbedding(in_channel=node_dim, out_channel=embed_dim)
+        self.nbr_embed = MultipleInputEmbedding(in_channels=[node_dim, edge_dim], out_channel=embed_dim)
+        self.bos_token = nn.Parameter(torch.empty(historical_steps, embed_dim))
+        nn.init.normal_(self.bos_token, mean=0.0, std=0.02)
+        self.apply(init_weights)
+
+    def forward(self, x: torch.Tensor, t: Optional[int], edge_index: Optional[torch.Tensor],
+                edge_attr: Optional[torch.Tensor], bos_mask: torch.Tensor, rotate_mat: Optional[torch.Tensor] = None,
+                size=None, edges: Optional[EdgeSet] = None) -> torch.Tensor:
+        """``parallel`` modules (or ``t is None``) take x [T*N, 2], bos_mask [N, T] and node ids
+        ``t*N + n``; otherwise x [N, 2], an integer ``t`` and bos_mask [N].  ``edges`` may carry the
+        already grouped edge set instead of ``edge_index`` / ``edge_attr``."""
+        T = self.historical_steps
+        batched = self.parallel or t is None
+        if batched:
+            n = x.shape[0] // T
+            xv = x.view(T, n, -1)
+            if rotate_mat is not None:
+                xv = torch.matmul(xv.unsqueeze(-2), rotate_mat.expand(T, *rotate_mat.shape)).squeeze(-2)
+            center = self.center_embed(xv)
+            center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2), center).reshape(x.shape[0], -1)
+            rot_mod = n
+        else:
+            xr = x if rotate_mat is None else torch.bmm(x.unsqueeze(-2), rotate_mat).squeeze(-2)
+            center = self.center_embed(xr)
+            center = torch.where(bos_mask.unsqueeze(-1), self.bos_token[t], center)
+            rot_mod = x.shape[0]
+        if edges is None:
+            edges = _edge_set_from_coo(edge_index, edge_attr, x.shape[0], x.shape[0])
+        center = center + self._mha_block(self.norm1(center), x, edges, rotate_mat, rot_mod)
+        center = center + self._ff_block(self.norm2(center))
+        return center
+
+    def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
+                   rot_mod: int) -> torch.Tensor:
+        feat, _src, _dst = ops.edge_gather_rotate(x, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
+                                                  edges.perm, rot_mod)
+        return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges)
+
+
+class ALEncoder(_EdgeAttentionBase):
+    """Lane -> actor edge attention (``models/local_encoder.py:283-397``)."""
+
+    def __init__(self, node_dim: int, edge_dim: int, embed_dim: int, num_heads: int = 8, dropout: float = 0.1,
+                 **kwargs) -> None:
+        super().__init__(embed_dim, num_heads, dropout)
+        self.lane_embed = MultipleInputEmbedding(in_channels=[node_dim, edge_dim], out_channel=embed_dim)
+        self.is_intersection_embed = nn.Parameter(torch.empty(2, embed_dim))
+        self.turn_direction_embed = nn.Parameter(torch.empty(3, embed_dim))
+        self.traffic_control_embed = nn.Parameter(torch.empty(2, embed_dim))
+        for token in (self.is_intersection_embed, self.turn_direction_embed, self.traffic_control_embed):
+            nn.init.normal_(token, mean=0.0, std=0.02)
+        self.apply(init_weights)
+
+    def forward(self, x: Tuple[torch.Tensor, torch.Tensor], edge_index: Optional[torch.Tensor],
+                edge_attr: Optional[torch.Tensor], is_intersections: torch.Tensor, turn_directions: torch.Tensor,
+                traffic_controls: torch.Tensor, rotate_mat: Optional[torch.Tensor] = None, size=None,
+                edges: Optional[EdgeSet] = None) -> torch.Tensor:
+        x_lane, x_actor = x
+        if edges is None:
+            edges = _edge_set_from_coo(edge_index, edge_attr, x_lane.shape[0], x_actor.shape[0])
+        # one code per lane for the three categorical attributes, one table row per code
+        code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
+        x_actor = x_actor + self._mha_block(self.norm1(x_actor), x_lane, edges, code, rotate_mat)
+        x_actor = x_actor + self._ff_block(self.norm2(x_actor))
+        return x_actor
+
+    def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
+                   rotate_mat: Optional[torch.Tensor]) -> torch.Tensor:
+        feat, src_csr, _dst = ops.edge_gather_rotate(x_lane, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
+                                                     edges.perm, x_actor.shape[0])
+        table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
+                 + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
+        cat_sum = table.index_select(0, lane_code.index_select(0, src_csr.long()))
+        return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, cat_sum), edges)
+
+
+# ----------------------------------------------------------------------------------------------
+# Temporal encoder (dense; stock attention kernels)
+# ----------------------------------------------------------------------------------------------
+class TemporalEncoderLayer(nn.Module):
+    """Pre-norm self-attention + feed-forward block (``models/local_encoder.py:244-280``)."""
+
+    def __init__(self, embed_dim: int, num_heads: int = 8, dropout: float = 0.1) -> None:
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=dropout)
+        self.linear1 = nn.Linear(embed_dim, embed_dim * 4)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(embed_dim * 4, embed_dim)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+
+    def _sa_block(self, x: torch.Tensor) -> torch.Tensor:
+        # causal self-attention over the time axis through the fused SDPA kernel; x is [S, N, D]
+        mha = self.self_attn
+        S, N, D = x.shape
+        H = mha.num_heads
+        qkv = F.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(S, N, 3, H, D // H)
+        q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))  # [N, H, S, d]
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=mha.dropout if self.training else 0.0, is_causal=True)
+        o = o.permute(2, 0, 1, 3).reshape(S, N, D)
+        return self.dropout1(mha.out_proj(o))
+
+    def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
+                src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
+        x = src + self._sa_block(self.norm1(src))
+        return x + self.dropout2(self.linear2(self.dropout(F.relu(self.linear1(self.norm2(x))))))
+
+
+class _EncoderStack(nn.Module):
+    """``layers`` + final ``norm`` under the key names of ``nn.TransformerEncoder``."""
+
+    def __init__(self, embed_dim: int, num_heads: int, num_layers: int, dropout: float) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList([TemporalEncoderLayer(embed_dim, num_heads, dropout) for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for layer in self.layers:
+            x = layer(x)
+        return self.norm(x)
+
+
+class TemporalEncoder(nn.Module):
+    """Causal transformer over the history with a trailing class token (``models/local_encoder.py:205-241``)."""
+
+    def __init__(self, historical_steps: int, embed_dim: int, num_heads: int = 8, num_layers: int = 4,
+                 dropout: float = 0.1) -> None:
+        super().__init__()
+        self.transformer_encoder = _EncoderStack(embed_dim, num_heads, num_layers, dropout)
+        self.padding_token = nn.Parameter(torch.empty(historical_steps, 1, embed_dim))
+        self.cls_token = nn.Parameter(torch.empty(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.empty(historical_steps + 1, 1, embed_dim))
+        self.register_buffer("attn_mask", self.generate_square_subsequent_mask(historical_steps + 1))
+        for token in (self.padding_token, self.cls_token, self.pos_embed):
+            nn.init.normal_(token, mean=0.0, std=0.02)
+        self.apply(init_weights)
+
+    def forward(self, x: torch.Tensor, padding_mask: torch.Tensor) -> torch.Tensor:
+        x = torch.where(padding_mask.t().unsqueeze(-1), self.padding_token, x)
+        x = torch.cat((x, self.cls_token.expand(-1, x.shape[1], -1)), dim=0) + self.pos_embed
+        return self.transformer_encoder(x)[-1]
+
+    @staticmethod
+    def generate_square_subsequent_mask(seq_len: int) -> torch.Tensor:
+        return torch.triu(torch.full((seq_len, seq_len), float("-inf")), diagonal=1)
+
+
+class LocalEncoder(nn.Module):
+    """``models/local_encoder.py:22-84`` with device-side edge construction and batched timesteps."""
+
+    def __init__(self, historical_steps: int, node_dim: int, edge_dim: int, embed_dim: int, num_heads: int = 8,
+                 dropout: float = 0.1, num_temporal_layers: int = 4, local_radius: float = 50,
+                 parallel: bool = False) -> None:
+        super().__init__()
+        self.historical_steps = historical_steps
+        self.parallel = parallel
+        self.local_radius = local_radius
+        self.drop_edge = DistanceDropEdge(local_radius)
+        self.aa_encoder = AAEncoder(historical_steps=historical_steps, node_dim=node_dim, edge_dim=edge_dim,
+                                    embed_dim=embed_dim, num_heads=num_heads, dropout=dropout, parallel=parallel)
+        self.temporal_encoder = TemporalEncoder(historical_steps=historical_steps, embed_dim=embed_dim,
+                                                num_heads=num_heads, dropout=dropout, num_layers=num_temporal_layers)
+        self.al_encoder = ALEncoder(node_dim=node_dim, edge_dim=edge_dim, embed_dim=embed_dim, num_heads=num_heads,
+                                    dropout=dropout)
+
+    def forward(self, data) -> torch.Tensor:
+        T = self.historical_steps
+        n = int(data.num_nodes)
+        plan = data.get("edge_plan")
+        if plan is None:
+            plan = build_edge_plan(data, T, self.local_radius)
+            data["edge_plan"] = plan
+        x_all = data["x"][:, :T].transpose(0, 1).reshape(T * n, -1)
+        out = self.aa_encoder(x=x_all, t=None, edge_index=None, edge_attr=None, bos_mask=data["bos_mask"],
+                              rotate_mat=data["rotate_mat"], edges=plan.agent_agent)
+        out = out.view(T, n, -1)
+        out = self.temporal_encoder(x=out, padding_mask=data["padding_mask"][:, :T])
+        out = self.al_encoder(x=(data["lane_vectors"], out), edge_index=None, edge_attr=None,
+                              is_intersections=data["is_intersections"], turn_directions=data["turn_directions"],
+                              traffic_controls=data["traffic_controls"], rotate_mat=data["rotate_mat"],
+                              edges=plan.lane_actor)
+        return out

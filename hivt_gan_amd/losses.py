@@ -1,0 +1,131 @@
+"""Loss modules with the reference's class names and call signatures (``losses/*.py``), plus the
+sync-free forms used by the training step: the fused supervised loss kernel and masked hinge / R1
+losses that take all agents with a keep-mask instead of boolean-indexed subsets."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _reduce(x: torch.Tensor, reduction: str) -> torch.Tensor:
+    if reduction == "mean":
+        return x.mean()
+    if reduction == "sum":
+        return x.sum()
+    if reduction == "none":
+        return x
+    raise ValueError(f"{reduction} is not a valid value for reduction")
+
+
+class LaplaceNLLLoss(nn.Module):
+    """``losses/laplace_nll_loss.py:4-36``: pred[..., 2:4] is a log-scale clamped to [-10, 10]."""
+
+    def __init__(self, eps: float = 1e-6, reduction: str = "mean") -> None:
+        super().__init__()
+        self.eps = eps
+        self.reduction = reduction
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        loc, log_scale = pred.chunk(2, dim=-1)
+        log_scale = log_scale.clamp(min=-10.0, max=10.0)
+        nll = log_scale + math.log(2.0) + (target - loc).abs() / (log_scale.exp() + self.eps)
+        return _reduce(nll, self.reduction)
+
+
+class SoftTargetCrossEntropyLoss(nn.Module):
+    """``losses/soft_target_cross_entropy_loss.py:6-23``."""
+
+    def __init__(self, reduction: str = "mean") -> None:
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return _reduce(-(target * F.log_softmax(pred, dim=-1)).sum(dim=-1), self.reduction)
+
+
+class R1Regularization(nn.Module):
+    """``losses/r1_regularization.py:5-36``: mean over samples of ||d D(x).sum() / dx||^2 (double-differentiable)."""
+
+    def forward(self, d_out: torch.Tensor, real_data: torch.Tensor) -> torch.Tensor:
+        (grad,) = torch.autograd.grad(outputs=d_out.sum(), inputs=real_data, create_graph=True, retain_graph=True,
+                                      only_inputs=True)
+        return grad.pow(2).reshape(grad.size(0), -1).sum(dim=1).mean()
+
+
+class AdversarialDiscriminatorLoss(nn.Module):
+    """Multi-scale hinge loss + R1 on real samples (``losses/adv_losses.py:7-58``)."""
+
+    def __init__(self, lambda_r1: float = 1.0) -> None:
+        super().__init__()
+        self.lambda_r1 = lambda_r1
+        self.r1_reg = R1Regularization()
+
+    def forward(self, critics: dict, real_trajs: dict, fake_trajs: dict):
+        total, logs = 0.0, {}
+        for name, critic in critics.items():
+            real = real_trajs[name].requires_grad_(True)
+            d_real, d_fake = critic(real), critic(fake_trajs[name].detach())
+            r1 = self.r1_reg(d_real, real)
+            loss = F.relu(1.0 - d_real).mean() + F.relu(1.0 + d_fake).mean() + self.lambda_r1 * r1
+            total = total + loss
+            logs[f"d_loss_{name}"] = loss.detach()
+            logs[f"r1_{name}"] = r1.detach()
+        return total, logs
+
+    def forward_masked(self, critics: dict, real: torch.Tensor, fake: torch.Tensor, keep: torch.Tensor):
+        """Same value as ``forward`` on ``real[keep]`` / ``fake[keep]`` sliced to each critic's horizon,
+        computed on all rows with ``keep`` as weights (no data-dependent shapes, no host sync).
+        Valid because every term is a per-sample mean and the critics act row-wise."""
+        w = keep.to(real.dtype)
+        cnt = w.sum().clamp(min=1.0)
+        total, logs = 0.0, {}
+        for name, critic in critics.items():
+            r = real.detach().clone().requires_grad_(True)
+            d_real, d_fake = critic(r), critic(fake.detach())
+            (grad,) = torch.autograd.grad(outputs=d_real.sum(), inputs=r, create_graph=True, retain_graph=True,
+                                          only_inputs=True)
+            r1 = (grad.pow(2).reshape(grad.size(0), -1).sum(dim=1) * w).sum() / cnt
+            loss = (F.relu(1.0 - d_real) * w).sum() / cnt + (F.relu(1.0 + d_fake) * w).sum() / cnt + self.lambda_r1 * r1
+            total = total + loss
+            logs[f"d_loss_{name}"] = loss.detach()
+            logs[f"r1_{name}"] = r1.detach()
+        return total, logs
+
+
+class AdversarialGeneratorLoss(nn.Module):
+    """``losses/adv_losses.py:62-99``."""
+
+    def __init__(self, lambda_adv: float = 1.0) -> None:
+        super().__init__()
+        self.lambda_adv = lambda_adv
+
+    def forward(self, critics: dict, fake_trajs: dict):
+        total, logs = 0.0, {}
+        for name, critic in critics.items():
+            g = -critic(fake_trajs[name]).mean()
+            total = total + g
+            logs[f"g_loss_{name}"] = g.detach()
+        return self.lambda_adv * total, logs
+
+    def forward_masked(self, critics: dict, fake: torch.Tensor, keep: torch.Tensor):
+        w = keep.to(fake.dtype)
+        cnt = w.sum().clamp(min=1.0)
+        total, logs = 0.0, {}
+        for name, critic in critics.items():
+            g = -(critic(fake) * w).sum() / cnt
+            total = total + g
+            logs[f"g_loss_{name}"] = g.detach()
+        return self.lambda_adv * total, logs
+
+
+def fused_supervised_losses(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
+                            historical_steps: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(reg_loss, cls_loss, best_mode) of ``HiVT._supervised_losses`` (``models/hivt.py:174-209``) through the
+    fused min-over-modes / Laplace-NLL / soft-target-CE kernel; zeros when no future step is valid."""
+    return ops.supervised_loss(y_hat, pi, y, padding_mask, historical_steps)

@@ -1,0 +1,389 @@
+"""torch.autograd.Functions and tensor-level wrappers over the C ABI of ``libhivt_mi355.so``.
+
+Everything here requires tensors resident on the GPU; there is no CPU implementation behind these
+functions.  PyTorch supplies device memory, the current stream and autograd bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _p(t: Optional[torch.Tensor], byte_offset: int = 0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + byte_offset)
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hivt_gan_amd kernels run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback in the product path")
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """A 2-D float32 view whose last dimension is contiguous (row stride arbitrary)."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.shape[0] > 1 and t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# Edge construction
+# --------------------------------------------------------------------------------------------
+def edges_temporal(edge_index: torch.Tensor, padding_mask: torch.Tensor, positions: torch.Tensor, t0: int, T: int,
+                   radius: Optional[float]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Validity sub-graph + relative positions + radius filter for timesteps ``t0..t0+T-1`` at once.
+
+    Returns capacity-sized ``src, dst`` (int32, node ids offset by ``(t-t0)*N``), ``attr`` (float [.,2])
+    and a device int32 ``count``; only the first ``count`` entries are meaningful.
+    """
+    _need_gpu(edge_index, padding_mask, positions)
+    edge_index = edge_index.contiguous()
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+    pm = padding_mask.contiguous()
+    pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
+    pos = positions.contiguous()
+    if pos.dtype != torch.float32 or pos.dim() != 3 or pos.shape[2] != 2:
+        raise ValueError("positions must be float32 [N, steps, 2]")
+    n = pos.shape[0]
+    if t0 < 0 or t0 + T > pm.shape[1] or t0 + T > pos.shape[1]:
+        raise ValueError("timestep range outside padding_mask / positions")
+    e0 = edge_index.shape[1]
+    cap = max(e0 * T, 1)
+    dev = pos.device
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = _lib.query("hivt_edges_workspace_bytes", e0 * T)
+    ws = _workspace(ws_bytes, dev)
+    _lib.call("hivt_edges_temporal", _p(edge_index), e0, _p(pm), pm.stride(0), _p(pos), pos.stride(0), pos.stride(1),
+              n, t0, T, float(radius) if radius is not None else 0.0, _p(src), _p(dst), _p(attr), _p(count), _p(ws),
+              ws.numel(), _stream(pos))
+    return src, dst, attr, count
+
+
+def edges_radius(edge_index: torch.Tensor, edge_attr: torch.Tensor, radius: Optional[float]
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Order-preserving radius filter of a COO edge list (lane -> actor edges)."""
+    _need_gpu(edge_index, edge_attr)
+    edge_index = edge_index.contiguous()
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+    attr_in = edge_attr.contiguous()
+    if attr_in.dtype != torch.float32 or attr_in.shape != (edge_index.shape[1], 2):
+        raise ValueError("edge_attr must be float32 [E, 2]")
+    e0 = edge_index.shape[1]
+    cap = max(e0, 1)
+    dev = attr_in.device
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _workspace(_lib.query("hivt_edges_workspace_bytes", e0), dev)
+    _lib.call("hivt_edges_radius", _p(edge_index), e0, _p(attr_in), float(radius) if radius is not None else 0.0,
+              _p(src), _p(dst), _p(attr), _p(count), _p(ws), ws.numel(), _stream(attr_in))
+    return src, dst, attr, count
+
+
+def csr_build(key: torch.Tensor, num_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable grouping of edge positions by ``key``: returns (rowptr int32 [num_rows+1], perm int32 [E])."""
+    _need_gpu(key)
+    if key.dtype != torch.int32 or key.dim() != 1:
+        raise ValueError("key must be an int32 vector")
+    key = key.contiguous()
+    e = key.shape[0]
+    dev = key.device
+    rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    ws = _workspace(_lib.query("hivt_csr_workspace_bytes", e, num_rows), dev)
+    _lib.call("hivt_csr_build", _p(key), e, num_rows, _p(rowptr), _p(perm), _p(ws), ws.numel(), _stream(key))
+    return rowptr, perm
+
+
+@dataclass
+class EdgeSet:
+    """One filtered edge list grouped by target node.
+
+    ``coo_*`` are in the order the reference would hold them (filtered, order preserving);
+    ``src`` / ``dst`` are the same edges in CSR order (position i of the CSR order is position
+    ``perm[i]`` of the COO order)."""
+    num_src: int
+    num_dst: int
+    coo_src: torch.Tensor
+    coo_dst: torch.Tensor
+    coo_attr: torch.Tensor
+    rowptr: torch.Tensor
+    perm: torch.Tensor
+    src: Optional[torch.Tensor] = None
+    dst: Optional[torch.Tensor] = None
+    rowptr_by_src: Optional[torch.Tensor] = None
+    perm_by_src: Optional[torch.Tensor] = None
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.coo_src.shape[0])
+
+    def edge_index(self) -> torch.Tensor:
+        """The filtered COO list as the reference's int64 ``[2, E]`` tensor."""
+        return torch.stack([self.coo_src, self.coo_dst]).long()
+
+    def group_by_source(self) -> None:
+        """CSR over sources of the CSR-ordered edges (for gradients of source lifts)."""
+        if self.rowptr_by_src is None:
+            self.rowptr_by_src, self.perm_by_src = csr_build(self.src, self.num_src)
+
+
+def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
+    """Group an already filtered int32 COO list by target."""
+    rowptr, perm = csr_build(dst, num_dst)
+    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm)
+
+
+# --------------------------------------------------------------------------------------------
+# Kernel (a): gather + rotate
+# --------------------------------------------------------------------------------------------
+class _EdgeGatherRotate(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x_src, attr, rot, src, dst, perm, rot_mod):
+        _need_gpu(x_src, attr, src, dst)
+        x2 = x_src if (x_src.dim() == 2 and x_src.stride(1) == 1 and x_src.stride(0) % 2 == 0
+                       and x_src.data_ptr() % 8 == 0) else x_src.contiguous()
+        attr = attr.contiguous()
+        rot_c = rot.contiguous() if rot is not None else None
+        e = src.shape[0]
+        out = torch.empty(e, 4, dtype=torch.float32, device=attr.device)
+        src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
+        dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
+        _lib.call("hivt_edge_gather_rotate_fwd", _p(x2), x2.stride(0), _p(attr), _p(rot_c), _p(src), _p(dst), _p(perm),
+                  int(rot_mod), e, _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
+        ctx.save_for_backward(rot_c, src, dst, perm)
+        ctx.rot_mod = int(rot_mod)
+        ctx.x_shape = tuple(x_src.shape)
+        ctx.mark_non_differentiable(src_csr, dst_csr)
+        return out, src_csr, dst_csr
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out, _g1, _g2):
+        rot_c, src, dst, perm = ctx.saved_tensors
+        e = src.shape[0]
+        d_out = d_out.contiguous()
+        d_x = torch.zeros(ctx.x_shape[0], 2, dtype=torch.float32, device=d_out.device) if ctx.needs_input_grad[0] \
+            else None
+        d_attr = torch.empty(e, 2, dtype=torch.float32, device=d_out.device) if ctx.needs_input_grad[1] else None
+        if d_x is not None or d_attr is not None:
+            _lib.call("hivt_edge_gather_rotate_bwd", _p(d_out), _p(rot_c), _p(src), _p(dst), _p(perm), ctx.rot_mod, e,
+                      _p(d_attr), _p(d_x), _stream(d_out))
+        if d_x is not None and ctx.x_shape[1] != 2:
+            full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=d_out.device)
+            full[:, :2] = d_x
+            d_x = full
+        return d_x, d_attr, None, None, None, None, None
+
+
+def edge_gather_rotate(x_src: torch.Tensor, attr: torch.Tensor, rot: Optional[torch.Tensor], src: torch.Tensor,
+                       dst: torch.Tensor, perm: Optional[torch.Tensor], rot_mod: int
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``[x_src[src] @ R[dst % rot_mod], attr @ R[dst % rot_mod]]`` per edge in ``perm`` order -> ([E,4], src, dst)."""
+    return _EdgeGatherRotate.apply(x_src, attr, rot, src, dst, perm, rot_mod)
+
+
+def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
+                 perm: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Global-interactor edge features ``[rel_pos @ R[dst], cos dtheta, sin dtheta]`` (inputs carry no grad)."""
+    _need_gpu(attr, rot, angles, src, dst)
+    e = src.shape[0]
+    attr, rot, angles = attr.contiguous(), rot.contiguous(), angles.contiguous()
+    out = torch.empty(e, 4, dtype=torch.float32, device=attr.device)
+    src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
+    dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
+    _lib.call("hivt_edge_relpose_fwd", _p(attr), _p(rot), _p(angles), _p(src), _p(dst), _p(perm), e, _p(out),
+              _p(src_csr), _p(dst_csr), _stream(attr))
+    return out, src_csr, dst_csr
+
+
+# --------------------------------------------------------------------------------------------
+# Kernels (b)+(c): segment softmax attention
+# --------------------------------------------------------------------------------------------
+def _fresh_seed() -> int:
+    # CPU generator: no device synchronisation, reproducible under torch.manual_seed
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+class _SegAttn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed):
+        _need_gpu(q, kv, rowptr)
+        n, d_model = q.shape
+        e = kv.shape[0]
+        if kv.shape[1] != 2 * d_model:
+            raise ValueError(f"kv must be [E, 2*D] (K | V), got {tuple(kv.shape)} for D={d_model}")
+        if rowptr.shape[0] != n + 1:
+            raise ValueError("rowptr must have num_targets + 1 entries")
+        q = q.contiguous()
+        kv = _rows(kv)
+        if kv_node is not None:
+            kv_node = _rows(kv_node)
+            if src is None or src.shape[0] != e:
+                raise ValueError("node terms need the per-edge source ids in CSR order")
+        out = torch.empty(n, d_model, dtype=torch.float32, device=q.device)
+        m = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
+        den = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
+        fb = 4 * d_model
+        _lib.call("hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
+                  _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
+                  kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
+                  _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _p(out), _p(m), _p(den), 0,
+                  _stream(q))
+        ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den)
+        ctx.cfg = (num_heads, float(dropout_p), int(seed))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den = ctx.saved_tensors
+        num_heads, dropout_p, seed = ctx.cfg
+        n, d_model = q.shape
+        e = kv.shape[0]
+        d_out = d_out.contiguous()
+        dq = torch.empty_like(q)
+        dkv = torch.empty(e, 2 * d_model, dtype=torch.float32, device=q.device)
+        fb = 4 * d_model
+        _lib.call("hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
+                  _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
+                  kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
+                  _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(dq), _p(dkv),
+                  _p(dkv, fb), 2 * d_model, 0, _stream(q))
+        dkv_node = None
+        if kv_node is not None and ctx.needs_input_grad[2]:
+            ns = kv_node.shape[0]
+            dkv_node = torch.empty(ns, 2 * d_model, dtype=torch.float32, device=q.device)
+            _lib.call("hivt_segment_sum_rows", _p(dkv), 2 * d_model, 2 * d_model, _p(rowptr_by_src), _p(perm_by_src),
+                      ns, _p(dkv_node), 2 * d_model, _stream(q))
+        return dq, dkv, dkv_node, None, None, None, None, None, None, None
+
+
+def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
+             training: bool = False, kv_node: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
+             rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None
+             ) -> torch.Tensor:
+    """Segment-softmax attention over CSR rows.
+
+    ``q`` [N,D]; ``kv`` [E,2D] holds K | V per edge in CSR order; optional ``kv_node`` [Ns,2D] adds the
+    source node's K | V (``src`` gives the source id of every CSR-ordered edge, and the CSR over
+    sources is needed for its gradient).  Returns the aggregated messages [N,D]."""
+    p = float(dropout_p) if training else 0.0
+    seed = _fresh_seed() if p > 0.0 else 0
+    if kv_node is not None and kv_node.requires_grad and (rowptr_by_src is None or perm_by_src is None):
+        raise ValueError("gradient of the node terms needs the CSR over sources")
+    return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed)
+
+
+# --------------------------------------------------------------------------------------------
+# Gated update
+# --------------------------------------------------------------------------------------------
+class _GatedUpdate(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, agg, ih, hh_self):
+        _need_gpu(agg, ih, hh_self)
+        n, d_model = agg.shape
+        agg, ih, hs = _rows(agg), _rows(ih), _rows(hh_self)
+        if hs.shape != (n, 2 * d_model) or ih.shape != (n, d_model):
+            raise ValueError("gated_update expects agg [N,D], ih [N,D], hh_self [N,2D]")
+        out = torch.empty(n, d_model, dtype=torch.float32, device=agg.device)
+        _lib.call("hivt_gated_update_fwd", _p(agg), agg.stride(0), _p(ih), ih.stride(0), _p(hs), hs.stride(0),
+                  _p(hs, 4 * d_model), hs.stride(0), n, d_model, _p(out), _stream(agg))
+        ctx.save_for_backward(agg, ih, hs)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        agg, ih, hs = ctx.saved_tensors
+        n, d_model = agg.shape
+        d_out = d_out.contiguous()
+        d_agg = torch.empty(n, d_model, dtype=torch.float32, device=agg.device)
+        d_ih = torch.empty(n, d_model, dtype=torch.float32, device=agg.device)
+        d_hs = torch.empty(n, 2 * d_model, dtype=torch.float32, device=agg.device)
+        _lib.call("hivt_gated_update_bwd", _p(d_out), _p(agg), agg.stride(0), _p(ih), ih.stride(0), _p(hs),
+                  hs.stride(0), _p(hs, 4 * d_model), hs.stride(0), n, d_model, _p(d_agg), _p(d_ih), _p(d_hs),
+                  2 * d_model, _p(d_hs, 4 * d_model), 2 * d_model, _stream(agg))
+        return d_agg, d_ih, d_hs
+
+
+def gated_update(agg: torch.Tensor, ih: torch.Tensor, hh_self: torch.Tensor) -> torch.Tensor:
+    """``agg + sigmoid(ih + hh) * (self - agg)`` with ``hh_self = [hh | self]`` of shape [N, 2D]."""
+    return _GatedUpdate.apply(agg, ih, hh_self)
+
+
+# --------------------------------------------------------------------------------------------
+# Fused supervised loss
+# --------------------------------------------------------------------------------------------
+class _SupervisedLoss(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, y_hat, pi, y, padding_mask, t_hist):
+        _need_gpu(y_hat, pi, y, padding_mask)
+        f, n, hf, ch = y_hat.shape
+        if ch != 4 or pi.shape != (n, f) or y.shape != (n, hf, 2):
+            raise ValueError("expected y_hat [F,N,H,4], pi [N,F], y [N,H,2]")
+        y_hat, pi, y = y_hat.contiguous(), pi.contiguous(), y.contiguous()
+        pm = padding_mask.contiguous()
+        pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
+        dev = y_hat.device
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        best = torch.empty(n, dtype=torch.int64, device=dev)
+        soft = torch.empty(n, f, dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("hivt_laplace_workspace_bytes", n), dev)
+        _lib.call("hivt_laplace_minmode_fwd", _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), int(t_hist), f, n, hf,
+                  _p(losses), _p(best), _p(soft), _p(stats), _p(ws), ws.numel(), _stream(y_hat))
+        ctx.save_for_backward(y_hat, pi, y, pm, best, soft, stats)
+        ctx.t_hist = int(t_hist)
+        ctx.mark_non_differentiable(best)
+        return losses, best
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_losses, _g_best):
+        y_hat, pi, y, pm, best, soft, stats = ctx.saved_tensors
+        f, n, hf, _ = y_hat.shape
+        g = g_losses.contiguous().float()
+        d_y_hat = torch.empty_like(y_hat)
+        d_pi = torch.empty_like(pi)
+        _lib.call("hivt_laplace_minmode_bwd", _p(g), _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), ctx.t_hist, f, n,
+                  hf, _p(best), _p(soft), _p(stats), _p(d_y_hat), _p(d_pi), _stream(y_hat))
+        return d_y_hat, d_pi, None, None, None
+
+
+def supervised_loss(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
+                    historical_steps: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(reg_loss, cls_loss, best_mode) of the best-of-F Laplace NLL + soft-target CE, without host sync."""
+    losses, best = _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps)
+    return losses[0], losses[1], best

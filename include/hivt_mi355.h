@@ -1,0 +1,204 @@
+/* libhivt_mi355 -- C ABI of the MI355X (gfx950) kernels behind HiVT-GAN's edge attention.
+ *
+ * Every entry point replaces a piece of the reference's Python / torch_geometric hot path; the
+ * comment above each one cites the reference lines (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes and strides (strides are in ELEMENTS of the
+ *     pointed-to type), no C++ or torch types;
+ *   - return value 0 = ok, negative = error (HIVT_ERR_*); hivt_last_error() returns the text of the
+ *     calling thread's last error (thread-local, valid until that thread's next failing call);
+ *   - all buffers are caller-owned; the library never allocates device memory.  Scratch comes from
+ *     a caller-provided workspace sized by the matching *_workspace_bytes() query (256-B aligned);
+ *   - every launch goes to the passed hipStream_t (as void*), is asynchronous, and performs no
+ *     host synchronisation; the library keeps no mutable global state and is re-entrant;
+ *   - row indices are int32; edge lists handed over by the framework (int64 [2,E] COO,
+ *     row 0 = source j, row 1 = target i) are converted by the edge-construction entry points;
+ *   - "CSR order" = edges sorted by target, ties in original list order (stable), which is the
+ *     accumulation order of the reference's CPU scatter_add_.
+ */
+#ifndef HIVT_MI355_H
+#define HIVT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIVT_OK 0
+#define HIVT_ERR_ARG (-1)     /* invalid argument (null pointer, bad size, unsupported D/H) */
+#define HIVT_ERR_WORKSPACE (-2) /* workspace missing or too small */
+#define HIVT_ERR_LAUNCH (-3)  /* HIP runtime reported a launch error */
+#define HIVT_ERR_UNSUPPORTED (-4) /* dtype or mode not built */
+
+#define HIVT_F32 0
+#define HIVT_BF16 1
+
+typedef void* hivt_stream_t; /* hipStream_t */
+
+/* Library version: major*10000 + minor*100 + patch. */
+int hivt_version(void);
+
+/* Text of the calling thread's last error ("" if none). */
+const char* hivt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge construction (bit-exact edge sets, order preserving)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Workspace for hivt_edges_temporal / hivt_edges_radius over `items` candidate edges. */
+size_t hivt_edges_workspace_bytes(int64_t items);
+
+/* Per-timestep agent-agent edges for timesteps t0 .. t0+T-1 in ONE launch sequence.
+ * Replaces, for every t: subgraph(~padding_mask[:, t], edge_index) + positions[src,t]-positions[dst,t]
+ * (models/local_encoder.py:58-61) + DistanceDropEdge (utils.py:69-78, strict ||.||_2 < radius;
+ * radius <= 0 disables the filter) and the snapshot batching with node id (t-t0)*N + n
+ * (models/local_encoder.py:62-71).  With t0 = T_hist-1, T = 1, radius <= 0 it is the edge set of
+ * GlobalInteractor.forward (models/global_interactor.py:48-50).
+ * Output lists are t-major and keep the input edge order inside a timestep.
+ *   edge_index    int64 [2,E0] (row stride E0)       padding_mask uint8/bool [N, pm_stride]
+ *   positions     float [N, *, 2] with element strides pos_stride_n / pos_stride_t
+ *   src_out/dst_out int32 [T*E0], attr_out float [T*E0,2], count_out int32 [1] (kept edges). */
+int hivt_edges_temporal(const int64_t* edge_index, int64_t E0, const uint8_t* padding_mask, int64_t pm_stride,
+                        const float* positions, int64_t pos_stride_n, int64_t pos_stride_t, int32_t N,
+                        int32_t t0, int32_t T, float radius, int32_t* src_out, int32_t* dst_out,
+                        float* attr_out, int32_t* count_out, void* workspace, size_t workspace_bytes,
+                        hivt_stream_t stream);
+
+/* Radius filter of a given edge list with given attributes (lane -> actor edges):
+ * DistanceDropEdge.__call__ (utils.py:69-78) as used at models/local_encoder.py:80. */
+int hivt_edges_radius(const int64_t* edge_index, int64_t E0, const float* edge_attr, float radius,
+                      int32_t* src_out, int32_t* dst_out, float* attr_out, int32_t* count_out,
+                      void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+
+/* Workspace for hivt_csr_build. */
+size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows);
+
+/* Stable counting sort of an edge list by `key` (target for the softmax/aggregate side, source
+ * for the node-gradient side): rowptr[r]..rowptr[r+1] index `perm`, and perm lists original edge
+ * positions in ascending order inside a row.  Replaces the implicit grouping done by
+ * torch_geometric's scatter in MessagePassing.propagate(aggr='add') and utils.softmax
+ * (call sites models/local_encoder.py:98,179,292,369; models/global_interactor.py:75,122).
+ *   key int32 [E] with values in [0,num_rows); rowptr int32 [num_rows+1]; perm int32 [E]. */
+int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, int32_t* rowptr, int32_t* perm,
+                   void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel (a): edge gather + rotation into the target's frame
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[e] = [ x_src[src[p]] @ R[dst[p] % rot_mod],  attr[p] @ R[dst[p] % rot_mod] ],  p = perm[e]
+ * (perm == NULL: p = e).  Replaces rotate_mat[edge_index[1]] + two torch.bmm + the x_j lift
+ * (models/local_encoder.py:169-173, 358-360).  rot == NULL copies without rotating
+ * (models/local_encoder.py:165-166, 352-356).  Also emits src/dst in the output order when
+ * src_csr / dst_csr are non-NULL.
+ *   x_src float [Ns, x_stride] (2 used), attr float [E,2], rot float [Nr,2,2] row-major,
+ *   out float [E,4]. */
+int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride, const float* attr, const float* rot,
+                                const int32_t* src, const int32_t* dst, const int32_t* perm, int32_t rot_mod,
+                                int64_t E, float* out, int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream);
+
+/* Gradient of the above w.r.t. attr (d_attr, original edge order, may be NULL) and x_src
+ * (d_x float [Ns,2], must be zero-filled by the caller, accumulated with float atomics, may be
+ * NULL).  Needed only when positions / features require grad (never in the reference's step). */
+int hivt_edge_gather_rotate_bwd(const float* d_out, const float* rot, const int32_t* src, const int32_t* dst,
+                                const int32_t* perm, int32_t rot_mod, int64_t E, float* d_attr, float* d_x,
+                                hivt_stream_t stream);
+
+/* Relative pose features of GlobalInteractor.forward (models/global_interactor.py:54-58):
+ * out[e] = [ attr[p] @ R[dst[p]],  cos(theta[src[p]]-theta[dst[p]]),  sin(...) ], p = perm[e]. */
+int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angles, const int32_t* src,
+                          const int32_t* dst, const int32_t* perm, int64_t E, float* out, int32_t* src_csr,
+                          int32_t* dst_csr, hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernels (b)+(c): per-edge QK dot, segment softmax over CSR rows, weighted sum of V
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[n,h,:] = sum_{e in row n} drop(softmax_e(q[n,h,:] . key_e[h,:] / sqrt(D/H))) * val_e[h,:]
+ * with key_e = k[e] (+ k_node[src[e]] when k_node != NULL), val_e likewise; softmax is
+ * exp(s - max) / (sum + 1e-16) per (row, head) exactly as torch_geometric.utils.softmax; rows
+ * without edges give zeros.  Replaces message()+aggregate of the three modules
+ * (models/local_encoder.py:174-181, 364-371 and :98, :292; models/global_interactor.py:115-124, :75).
+ * k / v rows are in CSR order with element stride kv_stride (so a fused [E,2D] K|V buffer works).
+ * Saves the per-(row,head) max `m_out` and denominator `den_out` (float [N,H]) for backward.
+ * Dropout (p > 0) uses a counter-based generator keyed on (seed, CSR position, head). */
+int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+                      const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
+                      int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
+                      float* m_out, float* den_out, int dtype, hivt_stream_t stream);
+
+/* Backward of hivt_seg_attn_fwd: dq float [N,D]; dk / dv float rows in CSR order with element
+ * stride dkv_stride (gradient of the per-edge key/value, i.e. also of k_node[src[e]] before it is
+ * summed per source -- use hivt_segment_sum_rows over a CSR-by-source for that).  The max is
+ * treated as a constant, as torch_geometric detaches it. */
+int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+                      const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
+                      const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
+                      int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
+                      float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream);
+
+/* out[r, 0:width] = sum_{i in rowptr[r]..rowptr[r+1]} rows[perm[i], 0:width] in ascending i
+ * (deterministic scatter-add without atomics; perm == NULL reads rows[i]).  Used for the
+ * gradient of x_j lifts (index_select backward), e.g. lin_k_node / lin_v_node outputs
+ * (models/global_interactor.py:116,118).  width must be a multiple of 4. */
+int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
+                          const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
+                          hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gated update (elementwise tail of update())
+ * ------------------------------------------------------------------------------------------ */
+
+/* out = agg + sigmoid(ih + hh) * (self_ - agg)  for float [N,D] operands with element row strides.
+ * Replaces the elementwise part of update() (models/local_encoder.py:187-188, 378-379;
+ * models/global_interactor.py:130-131); ih = lin_ih(agg), hh = lin_hh(c), self_ = lin_self(c). */
+int hivt_gated_update_fwd(const float* agg, int64_t agg_stride, const float* ih, int64_t ih_stride,
+                          const float* hh, int64_t hh_stride, const float* self_, int64_t self_stride,
+                          int64_t N, int32_t D, float* out, hivt_stream_t stream);
+
+/* Gradients of the above: d_agg (direct term only, contiguous [N,D]), the gate pre-activation
+ * gradient written twice -- d_ih (contiguous [N,D]) and d_hh (row stride d_hh_stride, may be NULL) --
+ * and d_self (row stride d_self_stride), so that hh | self may live in one fused [N,2D] buffer. */
+int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stride, const float* ih,
+                          int64_t ih_stride, const float* hh, int64_t hh_stride, const float* self_,
+                          int64_t self_stride, int64_t N, int32_t D, float* d_agg, float* d_ih, float* d_hh,
+                          int64_t d_hh_stride, float* d_self, int64_t d_self_stride, hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused regression / classification loss (min over modes + Laplace NLL + soft-target CE)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Workspace for hivt_laplace_minmode_fwd. */
+size_t hivt_laplace_workspace_bytes(int32_t N);
+
+/* Replaces HiVT._supervised_losses (models/hivt.py:174-209) with LaplaceNLLLoss.forward
+ * (losses/laplace_nll_loss.py:12-36, reduction 'mean') and SoftTargetCrossEntropyLoss.forward
+ * (losses/soft_target_cross_entropy_loss.py:12-23, reduction 'mean'):
+ *   l2[f,n]   = sum_h ||y_hat[f,n,h,0:2] - y[n,h]||_2 * valid[n,h]
+ *   best[n]   = argmin_f l2[f,n]   (first minimum)
+ *   reg_loss  = mean over valid (n,h) and 2 channels of  s + ln2 + |y - loc| / (exp(s) + 1e-6),
+ *               s = clamp(y_hat[best,n,h,2:4], -10, 10)
+ *   cls_loss  = mean over n with >=1 valid step of  -sum_f softmax_f(-l2/(cnt+1e-6)) * log_softmax(pi[n])_f
+ * valid[n,h] = !padding_mask[n, t_hist + h].  With no valid step at all both losses are 0.
+ *   y_hat float [F,N,Hf,4]; pi float [N,F]; y float [N,Hf,2]; padding_mask uint8 [N, pm_stride];
+ *   losses_out float [2] = {reg, cls}; best_out int64 [N]; stats_out float [4] =
+ *   {valid (n,h) count, rows with a valid step, 0, 0} (kept for backward). */
+int hivt_laplace_minmode_fwd(const float* y_hat, const float* pi, const float* y, const uint8_t* padding_mask,
+                             int64_t pm_stride, int32_t t_hist, int32_t F, int32_t N, int32_t Hf,
+                             float* losses_out, int64_t* best_out, float* soft_out, float* stats_out,
+                             void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+
+/* d_y_hat float [F,N,Hf,4] (written in full: zeros outside the best mode) and d_pi float [N,F]
+ * for upstream gradients g[0] (reg) and g[1] (cls) read from device memory `grad_losses`. */
+int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const float* pi, const float* y,
+                             const uint8_t* padding_mask, int64_t pm_stride, int32_t t_hist, int32_t F,
+                             int32_t N, int32_t Hf, const int64_t* best, const float* soft, const float* stats,
+                             float* d_y_hat, float* d_pi, hivt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIVT_MI355_H */
