@@ -1,0 +1,319 @@
+"""GPU parity of the reference-shaped modules and of the whole G + D + R1 step against the CPU
+oracle fed with the same state_dict and the same synthetic batch (dropout 0)."""
+import numpy as np
+import pytest
+import torch
+
+import hivt_gan_amd as hv
+from oracle import hivt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item()
+
+
+def assert_close(a, b, tol=1e-5, msg=""):
+    a_, b_ = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a_.shape == b_.shape, f"{msg}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
+    if b_.numel() == 0:
+        return
+    err = (a_ - b_).abs().max().item()
+    bound = tol * max(b_.abs().max().item(), 1e-3)
+    assert err <= bound, f"{msg}: max abs err {err:.3e} > {bound:.3e} (rel-to-max {err / max(b_.abs().max().item(), 1e-30):.2e})"
+
+
+def cpu_sd(module, prefix="m"):
+    return {f"{prefix}.{k}": v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point)
+            for k, v in module.state_dict().items()}
+
+
+# A bias added to every key shifts all scores of a (target, head) row by the same amount, and the
+# segment softmax is invariant to that: the exact gradient of these biases is zero and both the
+# oracle and the kernels hold only rounding noise there.
+# The same holds for the last bias of the mode-score head: it shifts all F logits of an agent alike
+# and the loss sees them only through log_softmax over modes.
+SHIFT_INVARIANT = ("lin_k.bias", "lin_k_node.bias", "lin_k_edge.bias", "decoder.pi.6.bias")
+
+
+def is_shift_invariant(name):
+    return name.endswith(SHIFT_INVARIANT)
+
+
+def compare_param_grads(module, sd, prefix="m", tol=1e-5):
+    params = dict(module.named_parameters())
+    scale = max(float(sd[f"{prefix}.{k}"].grad.abs().max()) for k in params if sd[f"{prefix}.{k}"].grad is not None)
+    checked, bad = 0, []
+    for k, p in params.items():
+        ref = sd[f"{prefix}.{k}"].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, f"missing grad for {k}"
+        if is_shift_invariant(k):
+            assert float(p.grad.abs().max()) <= tol * scale and float(ref.abs().max()) <= tol * scale, k
+            continue
+        try:
+            assert_close(p.grad, ref, tol, msg=k)
+        except AssertionError as exc:
+            bad.append(str(exc))
+        checked += 1
+    assert not bad, "\n".join(bad)
+    assert checked > 0
+
+
+def batch_tensors(b):
+    return {k: b[k] for k in b.keys()}
+
+
+@pytest.mark.parametrize("D,H,scenes", [(64, 8, 3), (128, 8, 2), (16, 2, 2)])
+def test_aa_encoder_per_timestep_and_batched(D, H, scenes):
+    torch.manual_seed(2022)
+    b = hv.make_batch(scenes)
+    data = batch_tensors(b)
+    ang = data["rotate_angles"]
+    rot = torch.stack([torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)], -1).view(-1, 2, 2)
+    mod = hv.AAEncoder(historical_steps=20, node_dim=2, edge_dim=2, embed_dim=D, num_heads=H, dropout=0.0).to(DEV)
+    mod.train()
+    sd = cpu_sd(mod)
+    # per-timestep call with the reference's arguments
+    for t in (0, 7, 19):
+        ei, ea = O.temporal_edges(data, t, 50.0)
+        ref = O.aa_encoder(sd, "m", data["x"][:, t], t, ei, ea, data["bos_mask"][:, t], rot, 20, H)
+        out = mod(x=data["x"][:, t].to(DEV), t=t, edge_index=ei.to(DEV), edge_attr=ea.to(DEV),
+                  bos_mask=data["bos_mask"][:, t].to(DEV), rotate_mat=rot.to(DEV))
+        assert_close(out, ref, msg=f"t={t}")
+    # batched over all timesteps, forward + backward
+    n = data["x"].shape[0]
+    eis, eas = [], []
+    for t in range(20):
+        ei, ea = O.temporal_edges(data, t, 50.0)
+        eis.append(ei + t * n)
+        eas.append(ea)
+    ei, ea = torch.cat(eis, 1), torch.cat(eas, 0)
+    x_all = data["x"].transpose(0, 1).reshape(20 * n, 2)
+    w = torch.randn(20 * n, D)
+    ref = O.aa_encoder(sd, "m", x_all, None, ei, ea, data["bos_mask"], rot, 20, H, parallel=True)
+    (ref * w).sum().backward()
+    out = mod(x=x_all.to(DEV), t=None, edge_index=ei.to(DEV), edge_attr=ea.to(DEV), bos_mask=data["bos_mask"].to(DEV),
+              rotate_mat=rot.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    assert_close(out, ref, msg="batched")
+    compare_param_grads(mod, sd)
+    # without rotation
+    ref2 = O.aa_encoder(sd, "m", data["x"][:, 5], 5, *O.temporal_edges(data, 5, 50.0), data["bos_mask"][:, 5], None, 20, H)
+    ei5, ea5 = O.temporal_edges(data, 5, 50.0)
+    out2 = mod(x=data["x"][:, 5].to(DEV), t=5, edge_index=ei5.to(DEV), edge_attr=ea5.to(DEV),
+               bos_mask=data["bos_mask"][:, 5].to(DEV), rotate_mat=None)
+    assert_close(out2, ref2, msg="no-rotate")
+
+
+@pytest.mark.parametrize("D,H,random_attrs", [(64, 8, True), (128, 8, False)])
+def test_al_encoder(D, H, random_attrs):
+    torch.manual_seed(7)
+    b = hv.make_batch(3, random_lane_attrs=random_attrs)
+    data = batch_tensors(b)
+    n = data["x"].shape[0]
+    ang = data["rotate_angles"]
+    rot = torch.stack([torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)], -1).view(-1, 2, 2)
+    mod = hv.ALEncoder(node_dim=2, edge_dim=2, embed_dim=D, num_heads=H, dropout=0.0).to(DEV)
+    mod.train()
+    sd = cpu_sd(mod)
+    x_actor = torch.randn(n, D)
+    ei, ea = O.distance_drop_edge(data["lane_actor_index"], data["lane_actor_vectors"], 30.0)
+    xa_c = x_actor.clone().requires_grad_(True)
+    ref = O.al_encoder(sd, "m", data["lane_vectors"], xa_c, ei, ea, data["is_intersections"],
+                       data["turn_directions"], data["traffic_controls"], rot, H)
+    w = torch.randn(n, D)
+    (ref * w).sum().backward()
+    xa_g = x_actor.to(DEV).requires_grad_(True)
+    out = mod(x=(data["lane_vectors"].to(DEV), xa_g), edge_index=ei.to(DEV), edge_attr=ea.to(DEV),
+              is_intersections=data["is_intersections"].to(DEV), turn_directions=data["turn_directions"].to(DEV),
+              traffic_controls=data["traffic_controls"].to(DEV), rotate_mat=rot.to(DEV))
+    (out * w.to(DEV)).sum().backward()
+    assert_close(out, ref)
+    assert_close(xa_g.grad, xa_c.grad, msg="d x_actor")
+    compare_param_grads(mod, sd)
+    # empty lane set: edge_index [2, 0]
+    out0 = mod(x=(torch.zeros(0, 2, device=DEV), xa_g.detach()), edge_index=torch.zeros(2, 0, dtype=torch.long, device=DEV),
+               edge_attr=torch.zeros(0, 2, device=DEV), is_intersections=torch.zeros(0, dtype=torch.uint8, device=DEV),
+               turn_directions=torch.zeros(0, dtype=torch.uint8, device=DEV),
+               traffic_controls=torch.zeros(0, dtype=torch.uint8, device=DEV), rotate_mat=rot.to(DEV))
+    ref0 = O.al_encoder(sd, "m", torch.zeros(0, 2), x_actor, torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, 2),
+                        torch.zeros(0, dtype=torch.uint8), torch.zeros(0, dtype=torch.uint8),
+                        torch.zeros(0, dtype=torch.uint8), rot, H)
+    assert_close(out0, ref0, msg="empty lanes")
+
+
+@pytest.mark.parametrize("D,H", [(64, 8), (128, 8)])
+def test_global_interactor_layer_and_stack(D, H):
+    torch.manual_seed(9)
+    b = hv.make_batch(4)
+    data = batch_tensors(b)
+    n = data["x"].shape[0]
+    layer = hv.GlobalInteractorLayer(embed_dim=D, num_heads=H, dropout=0.0).to(DEV)
+    layer.apply(hv.init_weights)
+    layer.train()
+    sd = cpu_sd(layer)
+    ei = O.subgraph(~data["padding_mask"][:, 19], data["edge_index"])
+    x = torch.randn(n, D)
+    r = torch.randn(ei.shape[1], D)
+    xc, rc = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    ref = O.global_interactor_layer(sd, "m", xc, ei, rc, H)
+    w = torch.randn(n, D)
+    (ref * w).sum().backward()
+    xg, rg = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    out = layer(xg, ei.to(DEV), rg)
+    (out * w.to(DEV)).sum().backward()
+    assert_close(out, ref)
+    assert_close(xg.grad, xc.grad, msg="dx")
+    assert_close(rg.grad, rc.grad, msg="d edge_attr")
+    compare_param_grads(layer, sd)
+
+    # the whole interactor on a batch (edges built on the device)
+    gi = hv.GlobalInteractor(historical_steps=20, embed_dim=D, edge_dim=2, num_modes=6, num_heads=H, num_layers=3,
+                             dropout=0.0, rotate=True).to(DEV)
+    gi.train()
+    sdg = cpu_sd(gi)
+    ang = data["rotate_angles"]
+    rot = torch.stack([torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)], -1).view(-1, 2, 2)
+    dc = dict(data)
+    dc["rotate_mat"] = rot
+    le = torch.randn(n, D)
+    lec = le.clone().requires_grad_(True)
+    refg = O.global_interactor(sdg, "m", dc, lec, 20, 6, 3, H)
+    wg = torch.randn(6, n, D)
+    (refg * wg).sum().backward()
+    g = b.to(DEV)
+    g["rotate_mat"] = rot.to(DEV)
+    leg = le.to(DEV).requires_grad_(True)
+    outg = gi(g, leg)
+    (outg * wg.to(DEV)).sum().backward()
+    assert_close(outg, refg)
+    assert_close(leg.grad, lec.grad, msg="d local_embed")
+    compare_param_grads(gi, sdg)
+
+
+CFG64 = dict(historical_steps=20, future_steps=30, num_modes=6, rotate=True, node_dim=2, edge_dim=2, embed_dim=64,
+             num_heads=8, dropout=0.0, num_temporal_layers=4, num_global_layers=3, local_radius=50.0, parallel=False)
+
+
+def test_hivt64_generator_forward_backward_vs_oracle():
+    """HiVT-64 generator forward + supervised loss + backward on a synthetic batch: the GPU path must
+    match the reference-faithful per-timestep CPU path in outputs, losses and every parameter gradient."""
+    torch.manual_seed(2022)
+    model = hv.HiVT(**CFG64, lr=5e-4, weight_decay=1e-4, T_max=64).to(DEV)
+    model.train()
+    b = hv.make_batch(8)
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    y_ref, pi_ref, y_rot = O.hivt_forward(sd, batch_tensors(b), dict(CFG64), training=False)
+    reg_ref, cls_ref, best_ref = O.supervised_losses(y_ref, pi_ref, y_rot, b["padding_mask"], 20)
+    (reg_ref + cls_ref).backward()
+    g = b.to(DEV)
+    y_hat, pi = model(g)
+    assert_close(g["y"], y_rot, msg="rotated targets")
+    reg, cls, best = model._supervised_losses(g, y_hat, pi)
+    (reg + cls).backward()
+    assert_close(y_hat, y_ref, 2e-5, msg="y_hat")
+    assert_close(pi, pi_ref, 2e-5, msg="pi")
+    assert_close(reg, reg_ref, msg="reg")
+    assert_close(cls, cls_ref, msg="cls")
+    valid = (~b["padding_mask"][:, 20:]).any(dim=1)
+    assert torch.equal(best.cpu()[valid], best_ref[valid])
+    worst = 0.0
+    bad = []
+    for k, p in model.named_parameters():
+        ref = sd[k].grad
+        if ref is None or is_shift_invariant(k):
+            continue
+        e = rel_err(p.grad, ref) if float(ref.abs().max()) > 0 else float(p.grad.abs().max())
+        worst = max(worst, e)
+        if e >= 5e-5:
+            bad.append(f"{k}: relative error {e:.2e}")
+    assert not bad, "\n".join(bad)
+    print(f"worst parameter-gradient relative error {worst:.2e}")
+
+
+def test_gan_step_gradients_vs_oracle():
+    """One G + D + R1 step (critic dropout 0): critic and generator gradients and all losses."""
+    torch.manual_seed(2022)
+    model = hv.HiVT(**CFG64, lr=5e-4, weight_decay=1e-4, T_max=64, use_gan=True, lambda_adv=0.1, lambda_r1=1.0).to(DEV)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    b = hv.make_batch(6, first_index=100)
+    full = model.state_dict()
+    gen_sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in full.items()
+              if not k.startswith("D_")}
+    cr_sd = {}
+    for k, v in full.items():
+        if k.startswith("D_"):
+            t = v.detach().cpu().clone()
+            cr_sd[k] = t.requires_grad_(True) if (k.endswith("weight_orig") or k.endswith("bias")) else t
+    cfg = dict(CFG64, lambda_adv=0.1, lambda_r1=1.0, critic_dropout=0.0)
+
+    # lr = 0 so the critic update between the two backwards leaves the weights in place
+    class Frozen:
+        def __init__(self):
+            self.grads = {}
+
+        def zero_grad(self, set_to_none=False):
+            pass
+
+        def step(self):
+            pass
+
+    opt_g, opt_d = Frozen(), Frozen()
+    ref = O.gan_step_grads(gen_sd, cr_sd, batch_tensors(b), cfg, training=True)
+    g = b.to(DEV)
+    grabbed = {}
+
+    def grab(group):
+        params = model.critic_parameters() if group == "critic" else model.generator_parameters()
+        names = {id(p): k for k, p in model.named_parameters()}
+        grabbed[group] = {names[id(p)]: p.grad.detach().clone() for p in params if p.grad is not None}
+        if group == "critic":
+            for p in params:
+                p.grad = None
+
+    logs = model.training_step(g, opt_g, opt_d, sync_grads=grab)
+    assert_close(logs["reg_loss"], ref["reg_loss"], msg="reg")
+    assert_close(logs["cls_loss"], ref["cls_loss"], msg="cls")
+    assert_close(logs["d_loss"], ref["d_loss"], 2e-5, msg="d_loss")
+    assert_close(logs["g_adv"], ref["g_adv"], 2e-5, msg="g_adv")
+    for k, gref in ref["d_grads"].items():
+        assert rel_err(grabbed["critic"][k], gref) < 1e-4, k
+    worst = 0.0
+    bad = []
+    for k, gref in ref["g_grads"].items():
+        if gref is None or is_shift_invariant(k):
+            continue
+        e = rel_err(grabbed["generator"][k], gref)
+        worst = max(worst, e)
+        if e >= 1e-4:
+            bad.append(f"{k}: {e:.2e}")
+    assert not bad, "\n".join(bad)
+    print(f"worst generator-gradient relative error in the GAN step {worst:.2e}")
+
+
+def test_r1_double_backward_coexists_with_custom_functions():
+    """create_graph=True through the critics while the generator graph (custom Functions) is alive."""
+    torch.manual_seed(1)
+    model = hv.HiVT(**CFG64, lr=5e-4, weight_decay=1e-4, T_max=64, use_gan=True).to(DEV)
+    model.train()
+    trainer = hv.GanTrainer(model, distributed=False)
+    b = hv.make_batch(4).to(DEV)
+    y0 = b["y"]
+    before = [p.detach().clone() for p in model.critic_parameters()[:2]] + [model.generator_parameters()[0].detach().clone()]
+    for _ in range(2):
+        b["y"] = y0
+        logs = trainer.step(b)
+    assert all(torch.isfinite(v).all() for v in logs.values())
+    after = [p.detach() for p in model.critic_parameters()[:2]] + [model.generator_parameters()[0].detach()]
+    assert all(not torch.equal(a, c) for a, c in zip(before, after))
