@@ -1,0 +1,203 @@
+"""Throughput of the G + D + R1 training step (scenes/sec) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One rank per GPU (RCCL all-reduce of the flat gradient buckets); every rank draws its own synthetic
+nuScenes-shaped batches of ``--scenes`` scenes (weak scaling).  A step is the whole of
+``HiVT.training_step``: device-side edge construction, generator forward, fused supervised loss,
+critic update with hinge + R1, generator update.  Rank 0 prints ONE JSON line.
+
+The ``roofline`` object describes the dominant edge-attention kernel (segment-softmax attention
+forward over all 20 timesteps' agent-agent edges): algorithmic bytes of one launch divided by its
+average duration, measured with device events around each of its launches inside the timed
+region.  ``cpu_baseline`` times the CPU oracle's restatement of the same step on a bounded sample
+of the same workload (rank 0, single-GPU runs only).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import hivt_gan_amd as hv  # noqa: E402
+from hivt_gan_amd import ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def model_config(embed_dim: int):
+    return dict(historical_steps=20, future_steps=30, num_modes=6, rotate=True, node_dim=2, edge_dim=2,
+                embed_dim=embed_dim, num_heads=8, dropout=0.1, num_temporal_layers=4, num_global_layers=3,
+                local_radius=50.0, parallel=False, lr=5e-4, weight_decay=1e-4, T_max=64, use_gan=True,
+                lambda_adv=0.1, lambda_r1=1.0, critic_steps=1, short_horizon=10, mid_horizon=20, critic_lr=1e-4)
+
+
+def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool) -> float:
+    """Algorithmic HBM bytes of one launch (fp32 rows, int32 CSR)."""
+    s = 4
+    if kind == "fwd":
+        b = e * (2 * d * s + 4) + n * (2 * d * s + 4) + n * h * 8
+        if node_terms:
+            b += n * 2 * d * s + e * 4
+    else:
+        b = e * (4 * d * s + 4) + n * (4 * d * s + 4)
+        if node_terms:
+            b += n * 4 * d * s + e * 4
+    return float(b)
+
+
+def cpu_baseline(embed_dim: int, scenes: int, steps: int):
+    """The CPU oracle's G + D + R1 step (forward, both backwards, both AdamW updates) on a bounded
+    sample of the same workload; returns scenes/sec on the host cores torch is allowed to use."""
+    from oracle import hivt_oracle as O
+    cfg = model_config(embed_dim)
+    torch.manual_seed(2022)
+    model = hv.HiVT(**cfg)
+    full = model.state_dict()
+    gen_sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in full.items()
+              if not k.startswith("D_")}
+    cr_sd = {}
+    for k, v in full.items():
+        if k.startswith("D_"):
+            t = v.detach().clone()
+            cr_sd[k] = t.requires_grad_(True) if (k.endswith("weight_orig") or k.endswith("bias")) else t
+    gen_params = [v for v in gen_sd.values() if v.requires_grad]
+    cr_params = [v for v in cr_sd.values() if v.requires_grad]
+    opt_g = torch.optim.AdamW(gen_params, lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    opt_d = torch.optim.AdamW(cr_params, lr=cfg["critic_lr"], weight_decay=0.0)
+    ocfg = dict(cfg)
+
+    def critic_update(grads):
+        for p, g in zip(cr_params, grads.values()):
+            p.grad = g
+        opt_d.step()
+
+    ocfg["critic_update"] = critic_update
+    times = []
+    for i in range(steps + 1):
+        batch = hv.make_batch(scenes, first_index=50_000 + i * scenes)
+        data = {k: batch[k] for k in batch.keys()}
+        t0 = time.perf_counter()
+        res = O.gan_step_grads(gen_sd, cr_sd, data, ocfg, training=True)
+        for p, k in zip(gen_params, [k for k, v in gen_sd.items() if v.requires_grad]):
+            p.grad = res["g_grads"][k]
+        opt_g.step()
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times[1:])  # first step is warm-up
+    return {"value": scenes / med, "unit": "scenes/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (+1 warm-up) of the CPU oracle's G+D+R1 step incl. AdamW on {scenes} "
+                      f"synthetic scenes, HiVT-{embed_dim} fp32, median {med * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--embed-dim", type=int, default=128)
+    ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    torch.manual_seed(2022)
+    model = hv.HiVT(**model_config(args.embed_dim)).to(dev)
+    model.train()
+    trainer = hv.GanTrainer(model)
+
+    # synthetic batches, resident in HBM before the timed region; distinct scenes per rank
+    pool = []
+    for i in range(args.pool):
+        b = hv.make_batch(args.scenes, first_index=(rank * args.pool + i) * args.scenes).to(dev)
+        pool.append((b, b["y"]))
+    torch.manual_seed(1000 + rank)  # dropout streams differ per rank
+
+    def run_step(i: int):
+        batch, y_raw = pool[i % len(pool)]
+        batch["y"] = y_raw            # forward rotates the targets in place on the batch object
+        batch["edge_plan"] = None     # edge construction belongs to the step
+        return trainer.step(batch)
+
+    for i in range(args.warmup):
+        run_step(i)
+    records = []
+    ops.SEG_ATTN_TIMING = records
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        logs = run_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.SEG_ATTN_TIMING = None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        groups = {}
+        for kind, tag, n, e, d, h, node_terms, ev0, ev1 in records:
+            groups.setdefault((kind, tag, node_terms, d, h), []).append((n, e, ev0.elapsed_time(ev1) * 1e-3))
+        roofline, extra = None, []
+        for (kind, tag, node_terms, d, h), rows in groups.items():
+            by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms) for n, e, _ in rows) / len(rows)
+            tm = sum(r[2] for r in rows) / len(rows)
+            entry = {"kernel": f"seg_attn_{kind}_kernel", "caller": tag, "bound": "hbm", "achieved": by / tm / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / tm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_launch": by, "avg_launch_us": tm * 1e6, "launches": len(rows),
+                     "edges_per_launch": sum(r[1] for r in rows) / len(rows),
+                     "rows_per_launch": sum(r[0] for r in rows) / len(rows)}
+            extra.append(entry)
+            # dominant kernel: the forward over all 20 timesteps' agent-agent edges (most bytes per step)
+            if kind == "fwd" and tag == "AAEncoder":
+                roofline = entry
+        result = {
+            "metric": "train scenes/sec (G+D+R1 step)", "value": world * args.scenes * args.steps / elapsed,
+            "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HiVT-{args.embed_dim} full G+D+R1 train step, {args.scenes} synthetic "
+                                   f"nuScenes-shaped scenes per GPU per step, dropout 0.1, AdamW x2",
+                       "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}"},
+            "roofline": roofline, "edge_attention_kernels": extra,
+            "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.embed_dim, args.cpu_scenes, args.cpu_steps)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,7 +61,7 @@ class GlobalInteractorLayer(nn.Module):
         kv_edge = _fused_linear(edge_attr, self.lin_k_edge, self.lin_v_edge)
         agg = ops.seg_attn(q, kv_edge, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
-                           perm_by_src=edges.perm_by_src)
+                           perm_by_src=edges.perm_by_src, tag=type(self).__name__)
         upd = ops.gated_update(agg, self.lin_ih(agg), _fused_linear(x, self.lin_hh, self.lin_self))
         return self.proj_drop(self.out_proj(upd))
 

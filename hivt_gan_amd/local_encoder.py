@@ -117,7 +117,8 @@ class _EdgeAttentionBase(nn.Module):
         embeddings already in CSR order (``local_encoder.py:174-188,197-199`` / ``:364-379,391-394``)."""
         kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
         q = self.lin_q(center)
-        agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training)
+        agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
+                           tag=type(self).__name__)
         upd = ops.gated_update(agg, self.lin_ih(agg), _fused_linear(center, self.lin_hh, self.lin_self))
         return self.proj_drop(self.out_proj(upd))
 

@@ -228,6 +228,25 @@ def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, sr
 # --------------------------------------------------------------------------------------------
 # Kernels (b)+(c): segment softmax attention
 # --------------------------------------------------------------------------------------------
+# When set to a list, every segment-attention launch appends
+# (kind, tag, rows, edges, D, H, has_node_terms, start_event, end_event) -- device events recorded on
+# the launch stream right around the kernel -- so a benchmark can price the kernel inside a real step.
+SEG_ATTN_TIMING = None
+
+
+def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
+    rec = SEG_ATTN_TIMING
+    if rec is None:
+        _lib.call(name, *args)
+        return
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record(torch.cuda.current_stream(dev))
+    _lib.call(name, *args)
+    ev1.record(torch.cuda.current_stream(dev))
+    rec.append((kind, tag, n, e, d_model, heads, node_terms, ev0, ev1))
+
+
 def _fresh_seed() -> int:
     # CPU generator: no device synchronisation, reproducible under torch.manual_seed
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -236,7 +255,7 @@ def _fresh_seed() -> int:
 class _SegAttn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed):
+    def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed, tag):
         _need_gpu(q, kv, rowptr)
         n, d_model = q.shape
         e = kv.shape[0]
@@ -254,27 +273,29 @@ class _SegAttn(torch.autograd.Function):
         m = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         den = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _lib.call("hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
+        _timed_call("fwd", tag, n, e, d_model, num_heads, kv_node is not None, q.device,
+                    "hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                  _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _p(out), _p(m), _p(den), 0,
-                  _stream(q))
+                    _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _p(out), _p(m), _p(den), 0,
+                    _stream(q))
         ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den)
-        ctx.cfg = (num_heads, float(dropout_p), int(seed))
+        ctx.cfg = (num_heads, float(dropout_p), int(seed), tag)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out):
         q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den = ctx.saved_tensors
-        num_heads, dropout_p, seed = ctx.cfg
+        num_heads, dropout_p, seed, tag = ctx.cfg
         n, d_model = q.shape
         e = kv.shape[0]
         d_out = d_out.contiguous()
         dq = torch.empty_like(q)
         dkv = torch.empty(e, 2 * d_model, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _lib.call("hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
+        _timed_call("bwd", tag, n, e, d_model, num_heads, kv_node is not None, q.device,
+                    "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
                   _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(dq), _p(dkv),
@@ -285,13 +306,13 @@ class _SegAttn(torch.autograd.Function):
             dkv_node = torch.empty(ns, 2 * d_model, dtype=torch.float32, device=q.device)
             _lib.call("hivt_segment_sum_rows", _p(dkv), 2 * d_model, 2 * d_model, _p(rowptr_by_src), _p(perm_by_src),
                       ns, _p(dkv_node), 2 * d_model, _stream(q))
-        return dq, dkv, dkv_node, None, None, None, None, None, None, None
+        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None
 
 
 def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
              training: bool = False, kv_node: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
-             rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None
-             ) -> torch.Tensor:
+             rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None,
+             tag: str = "") -> torch.Tensor:
     """Segment-softmax attention over CSR rows.
 
     ``q`` [N,D]; ``kv`` [E,2D] holds K | V per edge in CSR order; optional ``kv_node`` [Ns,2D] adds the
@@ -301,7 +322,7 @@ def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads:
     seed = _fresh_seed() if p > 0.0 else 0
     if kv_node is not None and kv_node.requires_grad and (rowptr_by_src is None or perm_by_src is None):
         raise ValueError("gradient of the node terms needs the CSR over sources")
-    return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed)
+    return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed, tag)
 
 
 # --------------------------------------------------------------------------------------------
