@@ -208,7 +208,10 @@ class ALEncoder(_EdgeAttentionBase):
                                                      edges.perm, x_actor.shape[0])
         table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
                  + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
-        cat_sum = table.index_select(0, lane_code.index_select(0, src_csr.long()))
+        # rows of the 12-entry table picked per edge as a one-hot GEMM: its backward is a dense
+        # [12, E] x [E, D] product instead of E*D contended atomic adds into 12 rows
+        one_hot = F.one_hot(lane_code.index_select(0, src_csr.long()), 12).to(table.dtype)
+        cat_sum = one_hot @ table
         return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, cat_sum), edges)
 
 
