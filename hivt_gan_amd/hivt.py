@@ -141,7 +141,10 @@ class HiVT(nn.Module):
                     continue
                 opt.zero_grad(set_to_none=False)
                 if sync_grads is not None:
+                    # the other ranks step with the averaged gradient; so must this one, or the
+                    # replicas drift apart.  Without data parallelism a skipped batch changes nothing.
                     sync_grads(group)
+                    opt.step()
             return {"skipped": torch.ones((), device=data["y"].device)}
 
         if self.check_finite and bool(torch.isnan(data["y"]).any()):  # models/hivt.py:264
