@@ -1,0 +1,654 @@
+// Dense projections of the edge-attention path on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+//   forward      Y = epilogue(X W^T + b [+ add])   with bias / residual / LayerNorm / ReLU fused
+//   data grad    dX = dY W
+//   weight grad  dW = dY^T X, db = colsum(dY)      split over rows, reduced in a fixed order
+//   LayerNorm(+ReLU) backward for the fused forward epilogue
+//
+// One core serves all three products.  A block of 256 threads (4 waves, one per SIMD) owns a
+// BM x BN output tile; every wave accumulates a 32 x 64 sub-tile in two 32x32 accumulators.  The
+// reduction dimension is walked in steps of 32 through a double-buffered LDS image laid out
+// [k][row] for both operands, so a wave's operand read is 32 consecutive floats per half-wave
+// (conflict-free) and one read feeds a whole MFMA.  Global loads of step k+1 are issued before
+// the MFMAs of step k and written to the other LDS buffer after them (one barrier per step).
+// fp32 in, fp32 accumulate: results equal an fmaf chain over k, which keeps the 1e-5 parity bar.
+#include "common.h"
+
+#include <math.h>
+
+namespace hivt {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;
+constexpr int kThreads = 256;
+
+enum Epilogue : int { EPI_NONE = 0, EPI_RELU = 1, EPI_LN = 2, EPI_LN_RELU = 3 };
+
+// Operand descriptor: logical matrix Op[row][red] (row = output index, red = reduction index).
+// TRANS = true : memory is [row][red] (contiguous along the reduction)  -> transposing stage
+// TRANS = false: memory is [red][row] (contiguous along the output row) -> straight copy
+struct Operand {
+  const float* p;
+  int64_t ld;     // leading dimension in floats
+  int32_t rows;   // valid output rows
+  int32_t red;    // valid reduction length
+  int32_t vec_ok; // 16-byte vector loads are legal (alignment + multiples of 4)
+};
+
+template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false>
+struct Stage {
+  static constexpr int PITCH = TRANS ? ROWS + 1 : ROWS + 4;
+  static constexpr int NVEC = ROWS * kBK / 4 / kThreads;  // float4 per thread per step
+  float4 v[NVEC];
+  unsigned ok;  // 4 validity bits per float4; applied when the values are written to LDS
+  float4 colsum = {0.f, 0.f, 0.f, 0.f};  // ACCUM: running sum of everything this thread staged
+
+  // Branch-free: every lane loads from a clamped in-bounds address; out-of-range values are zeroed
+  // later, in store(), so the loads of a step issue back to back and stay in flight under the MFMAs.
+  __device__ __forceinline__ void load(const Operand& op, int row0, int red0, int tid) {
+    ok = 0u;
+#pragma unroll
+    for (int r = 0; r < NVEC; ++r) {
+      const int idx = tid + r * kThreads;
+      int row, red;
+      if (TRANS) {
+        row = idx / (kBK / 4);
+        red = (idx % (kBK / 4)) * 4;
+      } else {
+        red = idx / (ROWS / 4);
+        row = (idx % (ROWS / 4)) * 4;
+      }
+      const int gr = row0 + row, gk = red0 + red;
+      // index along the contiguous dimension (4 consecutive elements) and along the strided one
+      const int fast = TRANS ? gk : gr, fast_n = TRANS ? op.red : op.rows;
+      const int slow = TRANS ? gr : gk, slow_n = TRANS ? op.rows : op.red;
+      const bool slow_ok = slow < slow_n;
+      const int slow_c = slow_ok ? slow : slow_n - 1;
+      if (VEC) {
+        // fast_n % 4 == 0 here: all four elements are valid or none is
+        const int fast_c = fast < fast_n ? fast : fast_n - 4;
+        v[r] = *reinterpret_cast<const float4*>(op.p + (int64_t)slow_c * op.ld + fast_c);
+        ok |= (slow_ok && fast < fast_n) ? (0xFu << (4 * r)) : 0u;
+      } else {
+        const float* base = op.p + (int64_t)slow_c * op.ld;
+        const int last = fast_n - 1;
+        v[r].x = base[min(fast + 0, last)];
+        v[r].y = base[min(fast + 1, last)];
+        v[r].z = base[min(fast + 2, last)];
+        v[r].w = base[min(fast + 3, last)];
+        unsigned m = 0u;
+        m |= (fast + 0 < fast_n) ? 1u : 0u;
+        m |= (fast + 1 < fast_n) ? 2u : 0u;
+        m |= (fast + 2 < fast_n) ? 4u : 0u;
+        m |= (fast + 3 < fast_n) ? 8u : 0u;
+        ok |= slow_ok ? (m << (4 * r)) : 0u;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* lds, int tid) {
+#pragma unroll
+    for (int r = 0; r < NVEC; ++r) {
+      const int idx = tid + r * kThreads;
+      const unsigned m = ok >> (4 * r);
+      float4 val;
+      val.x = (m & 1u) ? v[r].x : 0.0f;
+      val.y = (m & 2u) ? v[r].y : 0.0f;
+      val.z = (m & 4u) ? v[r].z : 0.0f;
+      val.w = (m & 8u) ? v[r].w : 0.0f;
+      if (ACCUM) {
+        colsum.x += val.x;
+        colsum.y += val.y;
+        colsum.z += val.z;
+        colsum.w += val.w;
+      }
+      if (TRANS) {
+        const int row = idx / (kBK / 4);
+        const int red = (idx % (kBK / 4)) * 4;
+        lds[(red + 0) * PITCH + row] = val.x;
+        lds[(red + 1) * PITCH + row] = val.y;
+        lds[(red + 2) * PITCH + row] = val.z;
+        lds[(red + 3) * PITCH + row] = val.w;
+      } else {
+        const int red = idx / (ROWS / 4);
+        const int row = (idx % (ROWS / 4)) * 4;
+        *reinterpret_cast<float4*>(lds + red * PITCH + row) = val;
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false>
+struct Core {
+  using SA = Stage<BM, TA, VEC, ACC_A>;
+  using SB = Stage<BN, TB, VEC>;
+  static constexpr int A_FLOATS = kBK * SA::PITCH;
+  static constexpr int B_FLOATS = kBK * SB::PITCH;
+  static constexpr int C_PITCH = BN + 4;
+  static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
+  static constexpr int C_FLOATS = BM * C_PITCH;
+  static constexpr int LDS_FLOATS = STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS;
+  static constexpr int WN = BN / 64;  // waves along the columns; each wave owns 32 x 64
+
+  // Accumulates the product over [red_begin, red_end) and leaves the BM x BN tile in lds as
+  // C[row][col] (pitch C_PITCH).  All threads of the block must call it.
+  // With ACC_A, *a_colsum receives this thread's sum of the operand-A values it staged.
+  __device__ static void run(const Operand& a, const Operand& b, int row0, int col0, int red_begin, int red_end,
+                             float* lds, float4* a_colsum = nullptr) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int lo = lane & 31, hi = lane >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    SA sa;
+    SB sb;
+    // buffer b of operand A starts at b * BUF, of operand B at b * BUF + A_FLOATS (plain integer
+    // offsets into the one __shared__ array, so every access stays an LDS instruction)
+    constexpr int BUF = A_FLOATS + B_FLOATS;
+    const int steps = (red_end - red_begin + kBK - 1) / kBK;
+    if (steps > 0) {
+      sa.load(a, row0, red_begin, tid);
+      sb.load(b, col0, red_begin, tid);
+      sa.store(lds, tid);
+      sb.store(lds + A_FLOATS, tid);
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const int cur = (s & 1) * BUF;
+      const int nxt = BUF - cur;
+      if (s + 1 < steps) {
+        sa.load(a, row0, red_begin + (s + 1) * kBK, tid);
+        sb.load(b, col0, red_begin + (s + 1) * kBK, tid);
+      }
+      const int ao = cur + wr * 32 + lo;
+      const int bo = cur + A_FLOATS + wc * 64 + lo;
+#pragma unroll
+      for (int kk = 0; kk < kBK; kk += 2) {
+        const float av = lds[ao + (kk + hi) * SA::PITCH];
+        const float b0 = lds[bo + (kk + hi) * SB::PITCH];
+        const float b1 = lds[bo + (kk + hi) * SB::PITCH + 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+      }
+      if (s + 1 < steps) {
+        sa.store(lds + nxt, tid);
+        sb.store(lds + nxt + A_FLOATS, tid);
+      }
+      __syncthreads();
+    }
+    if (ACC_A) *a_colsum = sa.colsum;
+    // accumulators -> LDS tile (the staging buffers are dead after the last barrier)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      lds[row * C_PITCH + wc * 64 + lo] = acc0[r];
+      lds[row * C_PITCH + wc * 64 + 32 + lo] = acc1[r];
+    }
+    __syncthreads();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward: Y = epilogue(X W^T + bias [+ add])
+// ---------------------------------------------------------------------------------------------
+struct FwdArgs {
+  Operand x, w;
+  const float* bias;
+  const float* add;
+  int64_t add_ld;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* y;
+  int64_t y_ld;
+  float* z;       // pre-LayerNorm values (LN epilogues, optional)
+  int64_t z_ld;
+  float* stats;   // [M,2] mean, rstd (LN epilogues)
+  int32_t M, N;
+};
+
+template <int BM, int BN, int EPI, bool VEC>
+__global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
+  using C = Core<BM, BN, true, true, VEC>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  Operand xa = a.x, wa = a.w;
+  C::run(xa, wa, row0, col0, 0, a.x.red, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < BM; r += 4) {
+    const int gr = row0 + r;
+    if (gr >= a.M) break;
+    float vals[BN / 64];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j) {
+      const int c = lane + 64 * j, gc = col0 + c;
+      float v = 0.0f;
+      if (gc < a.N) {
+        v = lds[r * C::C_PITCH + c] + (a.bias ? a.bias[gc] : 0.0f);
+        if (a.add) v += a.add[(int64_t)gr * a.add_ld + gc];
+      }
+      vals[j] = v;
+      sum += v;
+    }
+    if (EPI == EPI_LN || EPI == EPI_LN_RELU) {
+      const float mean = wave_sum(sum) / (float)a.N;
+      float sq = 0.0f;
+#pragma unroll
+      for (int j = 0; j < BN / 64; ++j) {
+        const float d = (col0 + lane + 64 * j < a.N) ? vals[j] - mean : 0.0f;
+        sq += d * d;
+      }
+      const float rstd = rsqrtf(wave_sum(sq) / (float)a.N + a.eps);
+      if (lane == 0 && a.stats) {
+        a.stats[2 * (int64_t)gr] = mean;
+        a.stats[2 * (int64_t)gr + 1] = rstd;
+      }
+#pragma unroll
+      for (int j = 0; j < BN / 64; ++j) {
+        const int gc = col0 + lane + 64 * j;
+        if (gc < a.N) {
+          if (a.z) a.z[(int64_t)gr * a.z_ld + gc] = vals[j];
+          float o = (vals[j] - mean) * rstd * a.gamma[gc] + a.beta[gc];
+          if (EPI == EPI_LN_RELU) o = fmaxf(o, 0.0f);
+          a.y[(int64_t)gr * a.y_ld + gc] = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < BN / 64; ++j) {
+        const int gc = col0 + lane + 64 * j;
+        if (gc < a.N) a.y[(int64_t)gr * a.y_ld + gc] = (EPI == EPI_RELU) ? fmaxf(vals[j], 0.0f) : vals[j];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient: dX[M,K] = dY[M,N] W[N,K]   (optionally masked by act > 0 of a ReLU output)
+// ---------------------------------------------------------------------------------------------
+struct BwdDataArgs {
+  Operand dy, w;
+  float* dx;
+  int64_t dx_ld;
+  int32_t M, K;
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
+  using C = Core<BM, BN, true, false, VEC>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  C::run(a.dy, a.w, row0, col0, 0, a.dy.red, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < BM; r += 4) {
+    const int gr = row0 + r;
+    if (gr >= a.M) break;
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j) {
+      const int c = lane + 64 * j, gc = col0 + c;
+      if (gc < a.K) a.dx[(int64_t)gr * a.dx_ld + gc] = lds[r * C::C_PITCH + c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: partial[chunk][n][k] = sum_{m in chunk} dY[m][n] X[m][k]; bias partials likewise
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  Operand dy, x;   // both [red = m][row]: dy rows = n, x rows = k
+  float* partial;  // [chunks][N][K]
+  float* bias_partial;  // [chunks][N] or null
+  int32_t N, K, M, chunk_rows;
+};
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
+  using C = Core<BM, BN, false, false, VEC, true>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  __shared__ float bsum[kThreads / (BM / 4)][BM];
+  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  const int chunk = blockIdx.z;
+  const int m_begin = chunk * a.chunk_rows;
+  const int m_end = min(a.M, m_begin + a.chunk_rows);
+  Operand dy = a.dy, x = a.x;
+  dy.red = m_end;
+  x.red = m_end;
+  float4 colsum;
+  C::run(dy, x, row0, col0, m_begin, m_end, lds, &colsum);
+  float* out = a.partial + (int64_t)chunk * a.N * a.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = wave; r < BM; r += 4) {
+    const int gr = row0 + r;
+    if (gr >= a.N) break;
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j) {
+      const int c = lane + 64 * j, gc = col0 + c;
+      if (gc < a.K) out[(int64_t)gr * a.K + gc] = lds[r * C::C_PITCH + c];
+    }
+  }
+  // bias gradient of this chunk = column sums of the dY rows this block staged (first column tile
+  // only): thread t staged columns 4*(t % (BM/4)) .. +3 of every row it touched
+  if (a.bias_partial != nullptr && blockIdx.y == 0) {
+    constexpr int QUADS = BM / 4, GROUPS = kThreads / QUADS;
+    const int q = threadIdx.x % QUADS, g = threadIdx.x / QUADS;
+    bsum[g][4 * q + 0] = colsum.x;
+    bsum[g][4 * q + 1] = colsum.y;
+    bsum[g][4 * q + 2] = colsum.z;
+    bsum[g][4 * q + 3] = colsum.w;
+    __syncthreads();
+    if (threadIdx.x < BM && row0 + threadIdx.x < a.N) {
+      float t = 0.0f;
+#pragma unroll
+      for (int i = 0; i < GROUPS; ++i) t += bsum[i][threadIdx.x];
+      a.bias_partial[(int64_t)chunk * a.N + row0 + threadIdx.x] = t;
+    }
+  }
+}
+
+// out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: four row slices are summed
+// independently (ascending r inside a slice) and then combined in slice order, so the result does
+// not depend on scheduling.  One block covers 64 columns; each thread sums one slice of one column.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
+                                                          int C, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;
+  const int per = (R + 3) / 4;
+  const int r0 = sl * per, r1 = min(R, r0 + per);
+  float s = 0.0f;
+  if (c < C) {
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(int64_t)(r + u) * pitch + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; r < r1; ++r) s += partial[(int64_t)r * pitch + c];
+  }
+  part[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) out[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (+ReLU) backward for y = [relu](gamma * (z - mean) * rstd + beta)
+//   dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy' * gamma,  dy' = dy * (y > 0)
+// One wave per row; per-block partial sums of dgamma = sum dy' * xhat and dbeta = sum dy'.
+// ---------------------------------------------------------------------------------------------
+template <int NPL>  // contiguous columns per lane (N <= 64 * NPL); lane owns columns lane*NPL .. +NPL-1
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int64_t dy_ld,
+                                                     const float* __restrict__ z, int64_t z_ld,
+                                                     const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int relu, int64_t M, int N, int vec, float* __restrict__ dz,
+                                                     int64_t dz_ld, float* __restrict__ partial /*[grid][2][N]*/) {
+  __shared__ float red[4][2][64 * NPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * NPL;
+  float g_[NPL], b_[NPL], dg[NPL], db[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    g_[j] = c0 + j < N ? gamma[c0 + j] : 0.0f;
+    b_[j] = c0 + j < N ? beta[c0 + j] : 0.0f;
+    dg[j] = 0.0f;
+    db[j] = 0.0f;
+  }
+  const float inv_n = 1.0f / (float)N;
+  const bool full = vec && (c0 + NPL <= N);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float zz[NPL], dd[NPL];
+    if (NPL == 2 && full) {
+      const float2 a = *reinterpret_cast<const float2*>(z + r * z_ld + c0);
+      const float2 b = *reinterpret_cast<const float2*>(dy + r * dy_ld + c0);
+      zz[0] = a.x; zz[NPL - 1] = a.y; dd[0] = b.x; dd[NPL - 1] = b.y;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        zz[j] = c0 + j < N ? z[r * z_ld + c0 + j] : 0.0f;
+        dd[j] = c0 + j < N ? dy[r * dy_ld + c0 + j] : 0.0f;
+      }
+    }
+    float xh[NPL], gg[NPL];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const bool in = c0 + j < N;
+      const float x = in ? (zz[j] - mean) * rstd : 0.0f;
+      float d = in ? dd[j] : 0.0f;
+      if (relu && !(x * g_[j] + b_[j] > 0.0f)) d = 0.0f;
+      xh[j] = x;
+      dg[j] += d * x;
+      db[j] += d;
+      gg[j] = d * g_[j];
+      s1 += gg[j];
+      s2 += gg[j] * x;
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+    float o[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) o[j] = rstd * (gg[j] - s1 - xh[j] * s2);
+    if (NPL == 2 && full) {
+      *reinterpret_cast<float2*>(dz + r * dz_ld + c0) = make_float2(o[0], o[NPL - 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j)
+        if (c0 + j < N) dz[r * dz_ld + c0 + j] = o[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    red[wave][0][c0 + j] = dg[j];
+    red[wave][1][c0 + j] = db[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    const int which = i / N, c = i % N;
+    partial[((int64_t)blockIdx.x * 2 + which) * N + c] =
+        ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans) {
+  Operand o;
+  o.p = p;
+  o.ld = ld;
+  o.rows = rows;
+  o.red = red;
+  // vector loads run along the contiguous dimension: the reduction if trans, else the row index
+  const int32_t fast_n = trans ? red : rows;
+  o.vec_ok = (aligned16(p) && ld % 4 == 0 && fast_n % 4 == 0 && fast_n >= 4) ? 1 : 0;
+  return o;
+}
+
+int pick_chunks(int64_t M, int tiles) {
+  // aim at ~2 blocks per CU overall, at least 256 rows per chunk
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t max_by_rows = (M + 255) / 256;
+  int64_t c = want < max_by_rows ? want : max_by_rows;
+  if (c < 1) c = 1;
+  if (c > 1024) c = 1024;
+  return (int)c;
+}
+
+}  // namespace
+}  // namespace hivt
+
+using namespace hivt;
+
+extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
+                               const float* add, int64_t add_ld, const float* gamma, const float* beta, float eps,
+                               int epilogue, int64_t M, int32_t N, int32_t K, float* y, int64_t y_ld, float* z,
+                               int64_t z_ld, float* stats, hivt_stream_t stream) {
+  const char* what = "hivt_linear_fwd";
+  HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LN_RELU, HIVT_ERR_ARG, "%s: unknown epilogue %d", what,
+               epilogue);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(x && w && y, HIVT_ERR_ARG, "%s: null pointer", what);
+  const bool ln = epilogue == EPI_LN || epilogue == EPI_LN_RELU;
+  HIVT_REQUIRE(!ln || (gamma && beta && N <= 128), HIVT_ERR_ARG,
+               "%s: LayerNorm epilogue needs gamma, beta and N <= 128 (N=%d)", what, N);
+  FwdArgs a{};
+  a.x = make_operand(x, x_ld, (int32_t)M, K, true);
+  a.w = make_operand(w, w_ld, N, K, true);
+  a.bias = bias; a.add = add; a.add_ld = add_ld; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = a.x.vec_ok && a.w.vec_ok;
+#define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
+  if (vec)                                                                                                   \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true>), grid, dim3(kThreads), 0, s, a);              \
+  else                                                                                                       \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, false>), grid, dim3(kThreads), 0, s, a);             \
+  break;
+  if (N <= 64) {
+    dim3 grid((unsigned)((M + 127) / 128), 1);
+    switch (epilogue) {
+      case EPI_NONE: HIVT_FWD_CASE(128, 64, EPI_NONE)
+      case EPI_RELU: HIVT_FWD_CASE(128, 64, EPI_RELU)
+      case EPI_LN: HIVT_FWD_CASE(128, 64, EPI_LN)
+      default: HIVT_FWD_CASE(128, 64, EPI_LN_RELU)
+    }
+  } else {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 127) / 128));
+    switch (epilogue) {
+      case EPI_NONE: HIVT_FWD_CASE(64, 128, EPI_NONE)
+      case EPI_RELU: HIVT_FWD_CASE(64, 128, EPI_RELU)
+      case EPI_LN: HIVT_FWD_CASE(64, 128, EPI_LN)
+      default: HIVT_FWD_CASE(64, 128, EPI_LN_RELU)
+    }
+  }
+#undef HIVT_FWD_CASE
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
+                                    int32_t N, int32_t K, float* dx, int64_t dx_ld, hivt_stream_t stream) {
+  const char* what = "hivt_linear_bwd_data";
+  HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(dy && w && dx, HIVT_ERR_ARG, "%s: null pointer", what);
+  BwdDataArgs a{};
+  a.dy = make_operand(dy, dy_ld, (int32_t)M, N, true);
+  a.w = make_operand(w, w_ld, K, N, false);  // W[n][k]: reduction index n is the row of the memory image
+  a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = a.dy.vec_ok && a.w.vec_ok;
+  if (K <= 64) {
+    dim3 grid((unsigned)((M + 127) / 128), 1);
+    if (vec)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true>), grid, dim3(kThreads), 0, s, a);
+    else
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, false>), grid, dim3(kThreads), 0, s, a);
+  } else {
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 127) / 128));
+    if (vec)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);
+    else
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, false>), grid, dim3(kThreads), 0, s, a);
+  }
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
+  const int chunks = pick_chunks(M, tiles);
+  return align_up((size_t)chunks * ((size_t)N * K + (size_t)N) * sizeof(float), 256);
+}
+
+extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                                 int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                 hivt_stream_t stream) {
+  const char* what = "hivt_linear_wgrad";
+  HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(dw != nullptr, HIVT_ERR_ARG, "%s: dw is null", what);
+  hipStream_t s = (hipStream_t)stream;
+  if (M == 0) {
+    HIVT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), s), what);
+    if (dbias) HIVT_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), s), what);
+    return HIVT_OK;
+  }
+  HIVT_REQUIRE(dy && x, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace && workspace_bytes >= hivt_linear_wgrad_workspace_bytes(M, N, K), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small", what);
+  const int tiles_n = (N + 63) / 64, tiles_k = (K + 127) / 128;
+  const int chunks = pick_chunks(M, tiles_n * tiles_k);
+  const int chunk_rows = (int)(((M + chunks - 1) / chunks + kBK - 1) / kBK * kBK);
+  const int real_chunks = (int)((M + chunk_rows - 1) / chunk_rows);
+  WgradArgs a{};
+  a.dy = make_operand(dy, dy_ld, N, (int32_t)M, false);
+  a.x = make_operand(x, x_ld, K, (int32_t)M, false);
+  a.partial = reinterpret_cast<float*>(workspace);
+  a.bias_partial = dbias ? a.partial + (size_t)real_chunks * N * K : nullptr;
+  a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
+  dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
+  if (a.dy.vec_ok && a.x.vec_ok)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, false>), grid, dim3(kThreads), 0, s, a);
+  HIVT_CHECK_LAUNCH(what);
+  const int cnt = N * K;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(256), 0, s, a.partial, real_chunks,
+                     (int64_t)cnt, cnt, dw);
+  HIVT_CHECK_LAUNCH(what);
+  if (dbias) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, a.bias_partial,
+                       real_chunks, (int64_t)N, N, dbias);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  return HIVT_OK;
+}
+
+extern "C" size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N) {
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return align_up((size_t)blocks * 2 * (size_t)N * sizeof(float), 256);
+}
+
+extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                           const float* gamma, const float* beta, int relu, int64_t M, int32_t N, float* dz,
+                           int64_t dz_ld, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                           hivt_stream_t stream) {
+  const char* what = "hivt_ln_bwd";
+  HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128, HIVT_ERR_ARG, "%s: N must be in [1,128] (N=%d)", what, N);
+  HIVT_REQUIRE(dgamma && dbeta, HIVT_ERR_ARG, "%s: null gradient output", what);
+  hipStream_t s = (hipStream_t)stream;
+  if (M == 0) {
+    HIVT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)N * sizeof(float), s), what);
+    HIVT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)N * sizeof(float), s), what);
+    return HIVT_OK;
+  }
+  HIVT_REQUIRE(dy && z && stats && gamma && beta && dz, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace && workspace_bytes >= hivt_ln_bwd_workspace_bytes(M, N), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small", what);
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  float* partial = reinterpret_cast<float*>(workspace);
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  const int vec = (al8(dy) && al8(z) && al8(dz) && dy_ld % 2 == 0 && z_ld % 2 == 0 && dz_ld % 2 == 0) ? 1 : 0;
+  if (N <= 64)
+    hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
+                       beta, relu, M, N, vec, dz, dz_ld, partial);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
+                       beta, relu, M, N, vec, dz, dz_ld, partial);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial, (int)blocks,
+                     (int64_t)2 * N, N, dgamma);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial + N, (int)blocks,
+                     (int64_t)2 * N, N, dbeta);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}

@@ -408,3 +408,115 @@ def supervised_loss(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padd
     """(reg_loss, cls_loss, best_mode) of the best-of-F Laplace NLL + soft-target CE, without host sync."""
     losses, best = _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps)
     return losses[0], losses[1], best
+
+
+# --------------------------------------------------------------------------------------------
+# Dense projections on the fp32 matrix cores
+# --------------------------------------------------------------------------------------------
+EPI_NONE, EPI_RELU, EPI_LN, EPI_LN_RELU = 0, 1, 2, 3
+
+
+def _rows2(t: torch.Tensor) -> torch.Tensor:
+    """2-D float32 view (leading dims flattened) whose last dimension has stride 1."""
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        t = t.reshape(-1, t.shape[-1])
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def linear_fused_supported(n_out: int, layer_norm: bool) -> bool:
+    """Whether hivt_linear_fwd has a kernel for this output width / epilogue."""
+    return (not layer_norm) or n_out <= 128
+
+
+class _FusedLinear(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps):
+        _need_gpu(x, weight)
+        lead = x.shape[:-1]
+        x2 = _rows2(x)
+        m, k = x2.shape
+        n = weight.shape[0]
+        if weight.shape[1] != k:
+            raise ValueError(f"weight {tuple(weight.shape)} does not match input width {k}")
+        w2 = _rows2(weight)
+        ln = gamma is not None
+        add2 = _rows2(add) if add is not None else None
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        z = torch.empty(m, n, dtype=torch.float32, device=x.device) if ln else None
+        stats = torch.empty(m, 2, dtype=torch.float32, device=x.device) if ln else None
+        epi = (EPI_LN_RELU if relu else EPI_LN) if ln else (EPI_RELU if relu else EPI_NONE)
+        gamma_c = gamma.contiguous() if ln else None
+        beta_c = beta.contiguous() if ln else None
+        bias_c = bias.contiguous() if bias is not None else None
+        _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias_c), _p(add2),
+                  add2.stride(0) if add2 is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi, m, n, k, _p(y),
+                  n, _p(z), n, _p(stats), _stream(x))
+        ctx.save_for_backward(x2, w2, z, stats, gamma_c, beta_c, y if (relu and not ln) else None)
+        ctx.cfg = (bool(relu), ln, tuple(lead), bias is not None, add is not None,
+                   tuple(add.shape) if add is not None else None)
+        return y.view(*lead, n)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w2, z, stats, gamma, beta, y_relu = ctx.saved_tensors
+        relu, ln, lead, has_bias, has_add, add_shape = ctx.cfg
+        m, k = x2.shape
+        n = w2.shape[0]
+        dev = x2.device
+        dy2 = _rows2(dy)
+        s = _stream(x2)
+        dgamma = dbeta = None
+        if ln:
+            dz = torch.empty(m, n, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+            ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
+            _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), n, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
+                      _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+        elif relu:
+            dz = dy2 * (y_relu > 0)
+        else:
+            dz = dy2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(m, k, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, _p(dx), k, s)
+            dx = dx.view(*lead, k)
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+            db = torch.empty(n, dtype=torch.float32, device=dev) if has_bias else None
+            ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
+            _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(x2), x2.stride(0), m, n, k, _p(dw), _p(db),
+                      _p(ws), ws.numel(), s)
+        dadd = dz.view(add_shape) if (has_add and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dadd, dgamma, dbeta, None, None
+
+
+def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                 add: Optional[torch.Tensor] = None, layer_norm: Optional[torch.nn.LayerNorm] = None,
+                 relu: bool = False) -> torch.Tensor:
+    """``[relu]([layer_norm](x @ weight.T + bias [+ add]))`` in one launch (exact fp32 on the matrix cores).
+
+    Falls back to the stock GPU ops only where no kernel exists for the shape (LayerNorm wider than
+    128 columns); CPU tensors are refused."""
+    _need_gpu(x, weight)
+    n = weight.shape[0]
+    if not linear_fused_supported(n, layer_norm is not None):
+        y = torch.nn.functional.linear(x, weight, bias)
+        if add is not None:
+            y = y + add
+        if layer_norm is not None:
+            y = layer_norm(y)
+        return torch.relu(y) if relu else y
+    gamma = layer_norm.weight if layer_norm is not None else None
+    beta = layer_norm.bias if layer_norm is not None else None
+    eps = layer_norm.eps if layer_norm is not None else 0.0
+    return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps)

@@ -168,6 +168,51 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
                           int64_t d_hh_stride, float* d_self, int64_t d_self_stride, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dense projections on the fp32 matrix cores (exact fp32: an fmaf chain over k)
+ * ------------------------------------------------------------------------------------------ */
+
+#define HIVT_EPI_NONE 0
+#define HIVT_EPI_RELU 1
+#define HIVT_EPI_LN 2
+#define HIVT_EPI_LN_RELU 3
+
+/* y = epilogue(x w^T + bias [+ add]) for x float [M,K] (row stride x_ld), w float [N,K] (nn.Linear
+ * layout, row stride w_ld), bias [N] or NULL, add [M,N] or NULL.  Epilogues: none, ReLU,
+ * LayerNorm(gamma, beta, eps) and LayerNorm + ReLU (N <= 128); the LayerNorm epilogues also write
+ * the pre-normalisation values z (optional) and per-row (mean, rstd) into stats [M,2].
+ * Replaces nn.Linear / nn.LayerNorm / nn.ReLU chains of the per-edge embedding MLPs
+ * (models/embedding.py:15-23,36-46), the K|V / Q / update / output projections
+ * (models/local_encoder.py:106-113, models/global_interactor.py:79-88) and the feed-forward blocks
+ * (models/local_encoder.py:117-122). */
+int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
+                    const float* add, int64_t add_ld, const float* gamma, const float* beta, float eps,
+                    int epilogue, int64_t M, int32_t N, int32_t K, float* y, int64_t y_ld, float* z,
+                    int64_t z_ld, float* stats, hivt_stream_t stream);
+
+/* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue). */
+int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
+                         int32_t K, float* dx, int64_t dx_ld, hivt_stream_t stream);
+
+/* Workspace for hivt_linear_wgrad. */
+size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
+
+/* dw[N,K] = dy^T x and dbias[N] = column sums of dy (dbias may be NULL), reduced over M in a fixed
+ * order (row chunks, then chunk order): bitwise reproducible. */
+int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                      int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                      hivt_stream_t stream);
+
+/* Workspace for hivt_ln_bwd. */
+size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N);
+
+/* Backward of the LayerNorm (+ReLU when relu != 0) epilogue: from dy, the saved pre-normalisation
+ * z and stats, computes dz [M,N], dgamma [N], dbeta [N] (N <= 128). */
+int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                const float* gamma, const float* beta, int relu, int64_t M, int32_t N, float* dz,
+                int64_t dz_ld, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused regression / classification loss (min over modes + Laplace NLL + soft-target CE)
  * ------------------------------------------------------------------------------------------ */
 

@@ -346,3 +346,74 @@ def test_fused_supervised_loss_all_padded_is_zero():
     (reg + cls).backward()
     assert reg.item() == 0.0 and cls.item() == 0.0
     assert torch.all(y_hat.grad == 0) and torch.all(pi.grad == 0) and torch.all(best == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense projections on the fp32 matrix cores
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,ln,relu,use_add", [
+    (1000, 128, 128, True, True, False), (777, 256, 128, True, True, True), (300, 128, 256, False, False, False),
+    (515, 128, 512, False, True, False), (64, 512, 128, False, False, False), (2500, 64, 64, True, False, False),
+    (130, 2, 128, True, True, False), (129, 16, 16, True, True, True), (50, 128, 60, False, False, False),
+    (1, 128, 128, True, False, False), (4099, 128, 768, False, False, False), (333, 32, 32, False, True, True)])
+def test_fused_linear_forward_backward(M, K, N, ln, relu, use_add):
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    add = torch.randn(M, N, generator=gen) if use_add else None
+    norm = torch.nn.LayerNorm(N) if ln else None
+    if ln:
+        with torch.no_grad():
+            norm.weight.copy_(1 + 0.3 * torch.randn(N, generator=gen))
+            norm.bias.copy_(0.2 * torch.randn(N, generator=gen))
+    gy = torch.randn(M, N, generator=gen)
+
+    def run(dtype):
+        xs, ws, bs = (t.to(dtype).clone().requires_grad_(True) for t in (x, w, b))
+        ad = add.to(dtype).clone().requires_grad_(True) if use_add else None
+        y = torch.nn.functional.linear(xs, ws, bs)
+        if ad is not None:
+            y = y + ad
+        g = be = None
+        if ln:
+            g = norm.weight.detach().to(dtype).clone().requires_grad_(True)
+            be = norm.bias.detach().to(dtype).clone().requires_grad_(True)
+            y = torch.nn.functional.layer_norm(y, (N,), g, be, 1e-5)
+        if relu:
+            y = torch.relu(y)
+        (y * gy.to(dtype)).sum().backward()
+        return y, [xs.grad, ws.grad, bs.grad, ad.grad if ad is not None else None, g.grad if ln else None,
+                   be.grad if ln else None]
+
+    y32, g32 = run(torch.float32)
+    y64, g64 = run(torch.float64)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    ag = add.to(DEV).requires_grad_(True) if use_add else None
+    norm_g = None
+    if ln:
+        norm_g = torch.nn.LayerNorm(N).to(DEV)
+        norm_g.load_state_dict(norm.state_dict())
+    y = ops.fused_linear(xg, wg, bg, add=ag, layer_norm=norm_g, relu=relu)
+    (y * gy.to(DEV)).sum().backward()
+    close64(y, y32, y64, msg="y")
+    grads = [xg.grad, wg.grad, bg.grad, ag.grad if use_add else None, norm_g.weight.grad if ln else None,
+             norm_g.bias.grad if ln else None]
+    for name, a, r32, r64 in zip(["dx", "dw", "db", "dadd", "dgamma", "dbeta"], grads, g32, g64):
+        if r64 is not None:
+            close64(a, r32, r64, msg=name)
+
+
+def test_fused_linear_strided_input_and_3d():
+    gen = torch.Generator().manual_seed(8)
+    feat = torch.randn(500, 4, generator=gen)
+    w = torch.randn(64, 2, generator=gen)
+    b = torch.randn(64, generator=gen)
+    fg = feat.to(DEV)
+    y = ops.fused_linear(fg[:, 2:4], w.to(DEV), b.to(DEV))
+    close(y, torch.nn.functional.linear(feat[:, 2:4], w, b))
+    x3 = torch.randn(20, 33, 64, generator=gen)
+    w3 = torch.randn(64, 64, generator=gen) / 8
+    y3 = ops.fused_linear(x3.to(DEV), w3.to(DEV), None, relu=True)
+    assert y3.shape == (20, 33, 64)
+    close(y3, torch.relu(torch.nn.functional.linear(x3, w3)))
