@@ -12,6 +12,8 @@ from typing import List, Optional, Sequence
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 def init_weights(m: nn.Module) -> None:
     """Xavier-uniform linears with zero bias, unit LayerNorm, N(0, 0.02) embeddings,
@@ -63,7 +65,10 @@ class SingleInputEmbedding(nn.Module):
         self.apply(init_weights)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.embed(x)
+        e = self.embed  # Linear, LN, ReLU, Linear, LN, ReLU, Linear, LN -> three fused launches
+        h = ops.fused_linear(x, e[0].weight, e[0].bias, layer_norm=e[1], relu=True)
+        h = ops.fused_linear(h, e[3].weight, e[3].bias, layer_norm=e[4], relu=True)
+        return ops.fused_linear(h, e[6].weight, e[6].bias, layer_norm=e[7], relu=False)
 
 
 class MultipleInputEmbedding(nn.Module):
@@ -78,27 +83,37 @@ class MultipleInputEmbedding(nn.Module):
                                         nn.Linear(out_channel, out_channel), nn.LayerNorm(out_channel))
         self.apply(init_weights)
 
+    def _fuse(self, branch_inputs: Sequence[torch.Tensor], extra: Optional[torch.Tensor]) -> torch.Tensor:
+        """Branch first layers (Linear+LN+ReLU, one launch each), then ALL second linears as one
+        product over the concatenated hidden rows ([h_0 | h_1 | ..] @ [W_0 | W_1 | ..]^T + sum of
+        biases, which equals the sum of the branch outputs), the categorical rows added in the same
+        epilogue as LN+ReLU, then Linear+LN."""
+        hidden = [ops.fused_linear(inp, br[0].weight, br[0].bias, layer_norm=br[1], relu=True)
+                  for br, inp in zip(self.module_list, branch_inputs)]
+        h = hidden[0] if len(hidden) == 1 else torch.cat(hidden, dim=-1)
+        weight = self.module_list[0][3].weight if len(hidden) == 1 else \
+            torch.cat([br[3].weight for br in self.module_list], dim=1)
+        bias = self.module_list[0][3].bias
+        for br in self.module_list[1:]:
+            bias = bias + br[3].bias
+        a = self.aggr_embed
+        h = ops.fused_linear(h, weight, bias, add=extra, layer_norm=a[0], relu=True)
+        return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
+
     def forward(self, continuous_inputs: List[torch.Tensor],
                 categorical_inputs: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
-        total = None
-        for branch, inp in zip(self.module_list, continuous_inputs):
-            h = branch(inp)
-            total = h if total is None else total + h
+        cat = None
         if categorical_inputs is not None:
             cat = categorical_inputs[0]
             for extra in categorical_inputs[1:]:
                 cat = cat + extra
-            total = total + cat
-        return self.aggr_embed(total)
+        return self._fuse(continuous_inputs, cat)
 
     def forward_packed(self, packed: torch.Tensor, categorical_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same computation for inputs packed side by side in one [E, sum(in_channels)] record
         (the layout the gather kernel emits)."""
-        total, col = None, 0
-        for branch, width in zip(self.module_list, self.in_channels):
-            h = branch(packed[:, col:col + width])
-            total = h if total is None else total + h
+        parts, col = [], 0
+        for width in self.in_channels:
+            parts.append(packed[:, col:col + width])
             col += width
-        if categorical_sum is not None:
-            total = total + categorical_sum
-        return self.aggr_embed(total)
+        return self._fuse(parts, categorical_sum)

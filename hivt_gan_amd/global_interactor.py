@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .embedding import MultipleInputEmbedding, SingleInputEmbedding, init_weights
-from .local_encoder import _edge_set_from_coo, _fused_linear, build_edge_plan
+from .local_encoder import _edge_set_from_coo, _feed_forward, _fused_linear, _linear, build_edge_plan
 from .ops import EdgeSet
 
 
@@ -56,17 +56,17 @@ class GlobalInteractorLayer(nn.Module):
 
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor) -> torch.Tensor:
         edges.group_by_source()
-        q = self.lin_q_node(x)
+        q = _linear(x, self.lin_q_node)
         kv_node = _fused_linear(x, self.lin_k_node, self.lin_v_node)
         kv_edge = _fused_linear(edge_attr, self.lin_k_edge, self.lin_v_edge)
         agg = ops.seg_attn(q, kv_edge, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
                            perm_by_src=edges.perm_by_src, tag=type(self).__name__)
-        upd = ops.gated_update(agg, self.lin_ih(agg), _fused_linear(x, self.lin_hh, self.lin_self))
-        return self.proj_drop(self.out_proj(upd))
+        upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(x, self.lin_hh, self.lin_self))
+        return self.proj_drop(_linear(upd, self.out_proj))
 
     def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
-        return self.mlp(x)
+        return _feed_forward(self.mlp, x)
 
 
 class GlobalInteractor(nn.Module):

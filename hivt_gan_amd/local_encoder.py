@@ -86,8 +86,17 @@ def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_sr
 
 
 def _fused_linear(x: torch.Tensor, a: nn.Linear, b: nn.Linear) -> torch.Tensor:
-    """[a(x) | b(x)] as one GEMM."""
-    return F.linear(x, torch.cat([a.weight, b.weight], dim=0), torch.cat([a.bias, b.bias], dim=0))
+    """[a(x) | b(x)] as one product."""
+    return ops.fused_linear(x, torch.cat([a.weight, b.weight], dim=0), torch.cat([a.bias, b.bias], dim=0))
+
+
+def _linear(x: torch.Tensor, lin: nn.Linear, relu: bool = False) -> torch.Tensor:
+    return ops.fused_linear(x, lin.weight, lin.bias, relu=relu)
+
+
+def _feed_forward(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Linear, ReLU, Dropout, Linear, Dropout (``local_encoder.py:117-122``) with the ReLU fused."""
+    return mlp[4](_linear(mlp[2](_linear(x, mlp[0], relu=True)), mlp[3]))
 
 
 class _EdgeAttentionBase(nn.Module):
@@ -116,14 +125,14 @@ class _EdgeAttentionBase(nn.Module):
         """message (Q.K, segment softmax, weighting) + aggregate + update + out_proj for per-edge
         embeddings already in CSR order (``local_encoder.py:174-188,197-199`` / ``:364-379,391-394``)."""
         kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
-        q = self.lin_q(center)
+        q = _linear(center, self.lin_q)
         agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            tag=type(self).__name__)
-        upd = ops.gated_update(agg, self.lin_ih(agg), _fused_linear(center, self.lin_hh, self.lin_self))
-        return self.proj_drop(self.out_proj(upd))
+        upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(center, self.lin_hh, self.lin_self))
+        return self.proj_drop(_linear(upd, self.out_proj))
 
     def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
-        return self.mlp(x)
+        return _feed_forward(self.mlp, x)
 
 
 class AAEncoder(_EdgeAttentionBase):
