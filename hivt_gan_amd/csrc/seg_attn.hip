@@ -11,6 +11,7 @@
 // wave or one block, so results are deterministic.
 #include "common.h"
 
+#include <hip/hip_ext.h>
 #include <math.h>
 
 namespace hivt {
@@ -44,7 +45,14 @@ struct SegAttnArgs {
   float* dk;
   float* dv;
   int64_t dkv_stride;
+  // optional: events that receive the kernel's own start / stop time stamps
+  hipEvent_t ev_start;
+  hipEvent_t ev_stop;
 };
+
+// exp through the hardware exp2: relative error ~1e-7 for arguments near 0 (the terms that carry
+// the softmax weight) and below 6e-8 * |x| elsewhere (terms whose weight is e^x itself).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
@@ -72,7 +80,7 @@ __device__ __forceinline__ float4 shfl_xor4(const float4& a, int o) {
 // Merge two online-softmax states (m, l, acc) <- (m, l, acc) (+) (m2, l2, acc2).
 __device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, float m2, float l2, const float4& acc2) {
   const float mn = fmaxf(m, m2);
-  const float c1 = expf(m - mn), c2 = expf(m2 - mn);
+  const float c1 = fast_exp(m - mn), c2 = fast_exp(m2 - mn);
   l = l * c1 + l2 * c2;
   acc.x = acc.x * c1 + acc2.x * c2;
   acc.y = acc.y * c1 + acc2.y * c2;
@@ -81,33 +89,45 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, flo
   m = mn;
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL>
+// WPN  = waves that share one target row (1, or 4 for long rows, merged through LDS)
+// SPLIT = short-row mode: every lane slot (LPR lanes) of a wave owns its OWN target row, so a wave
+//         serves 64/LPR rows at once and no slot merge is needed (requires WPN == 1)
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
 __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) {
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
-  constexpr int NPB = 4 / WPN;  // target rows per 256-thread block
+  constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
+  constexpr int RPW = SPLIT ? EPI : 1;
+  static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * NPB + wave / WPN;
-  const int win = wave % WPN;
-  if (n >= a.N) return;  // block-uniform when WPN == 4
   const int sub = lane / LPR;
   const int c = lane % LPR;
   const int h = c / LPH;
+  const int win = wave % WPN;
+  const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  if (!SPLIT && n >= a.N) return;  // block-uniform when WPN == 4
+  const bool row_ok = n < a.N;
+  const int nc = row_ok ? n : a.N - 1;
 
-  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
-  float4 qs = ldg4(a.q + (int64_t)n * D + 4 * c);
-  scale4(qs, a.scale_inv);
+  const int beg = a.rowptr[nc];
+  const int end = row_ok ? a.rowptr[nc + 1] : beg;
+  float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (end > beg) {  // rows without edges never need their query
+    qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+    scale4(qs, a.scale_inv);
+  }
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
 
   float m = kNegSentinel, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  constexpr int STRIDE = WPN * EPI;
-  for (int e0 = beg + win * EPI + sub; e0 < end; e0 += STRIDE * kUnroll) {
+  constexpr int STRIDE = SPLIT ? 1 : WPN * EPI;
+  const int first = SPLIT ? beg : beg + win * EPI + sub;
+  for (int e0 = first; e0 < end; e0 += STRIDE * kUnroll) {
     float4 kk[kUnroll], vv[kUnroll];
     float s[kUnroll];
     bool ok[kUnroll];
@@ -131,13 +151,13 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
       s[u] = ok[u] ? part : kNegSentinel;
       smax = fmaxf(smax, s[u]);
     }
-    const float corr = expf(m - smax);
+    const float corr = fast_exp(m - smax);
     l *= corr;
     scale4(acc, corr);
     m = smax;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      float p = ok[u] ? expf(s[u] - m) : 0.0f;
+      float p = ok[u] ? fast_exp(s[u] - m) : 0.0f;
       l += p;
       if (drop) {
         const uint64_t idx = (uint64_t)(e0 + u * STRIDE) * (uint64_t)a.H + (uint64_t)h;
@@ -147,12 +167,14 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
     }
   }
 
-  // merge the EPI lane slots of this wave
+  if (!SPLIT) {
+    // merge the EPI lane slots of this wave
 #pragma unroll
-  for (int o = LPR; o < kWave; o <<= 1) {
-    const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
-    const float4 acc2 = shfl_xor4(acc, o);
-    merge_state(m, l, acc, m2, l2, acc2);
+    for (int o = LPR; o < kWave; o <<= 1) {
+      const float m2 = __shfl_xor(m, o, 64), l2 = __shfl_xor(l, o, 64);
+      const float4 acc2 = shfl_xor4(acc, o);
+      merge_state(m, l, acc, m2, l2, acc2);
+    }
   }
 
   if (WPN > 1) {
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
     }
   }
 
-  if (sub == 0) {
+  if ((SPLIT || sub == 0) && row_ok) {
     const float den = l + 1e-16f;
     const float inv = 1.0f / den;
     *reinterpret_cast<float4*>(a.out + (int64_t)n * D + 4 * c) =
@@ -186,37 +208,47 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL>
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
 __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;
+  constexpr int RPW = SPLIT ? EPI : 1;
+  static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * NPB + wave / WPN;
-  const int win = wave % WPN;
-  if (n >= a.N) return;
   const int sub = lane / LPR;
   const int c = lane % LPR;
   const int h = c / LPH;
+  const int win = wave % WPN;
+  const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  if (!SPLIT && n >= a.N) return;
+  const bool row_ok = n < a.N;
+  const int nc = row_ok ? n : a.N - 1;
 
-  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
-  float4 qs = ldg4(a.q + (int64_t)n * D + 4 * c);
-  scale4(qs, a.scale_inv);
-  const float4 go = ldg4(a.d_out + (int64_t)n * D + 4 * c);
-  const float4 o4 = ldg4(a.out + (int64_t)n * D + 4 * c);
-  const float delta = group_sum<LPH>(dot4(go, o4));
-  const float mh = a.m[(int64_t)n * a.H + h];
-  const float inv_den = 1.0f / a.den[(int64_t)n * a.H + h];
+  const int beg = a.rowptr[nc];
+  const int end = row_ok ? a.rowptr[nc + 1] : beg;
+  float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs;
+  float delta = 0.0f, mh = 0.0f, inv_den = 0.0f;
+  if (end > beg) {
+    qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+    scale4(qs, a.scale_inv);
+    go = ldg4(a.d_out + (int64_t)nc * D + 4 * c);
+    const float4 o4 = ldg4(a.out + (int64_t)nc * D + 4 * c);
+    delta = group_sum<LPH>(dot4(go, o4));
+    mh = a.m[(int64_t)nc * a.H + h];
+    inv_den = 1.0f / a.den[(int64_t)nc * a.H + h];
+  }
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
 
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  constexpr int STRIDE = WPN * EPI;
-  for (int e0 = beg + win * EPI + sub; e0 < end; e0 += STRIDE * kUnroll) {
+  constexpr int STRIDE = SPLIT ? 1 : WPN * EPI;
+  const int first = SPLIT ? beg : beg + win * EPI + sub;
+  for (int e0 = first; e0 < end; e0 += STRIDE * kUnroll) {
     float4 kk[kUnroll], vv[kUnroll];
     bool ok[kUnroll];
 #pragma unroll
@@ -238,7 +270,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
       const float dav = group_sum<LPH>(dot4(go, vv[u]));
       if (ok[u]) {
         const int64_t e = e0 + u * STRIDE;
-        const float alpha = expf(s - mh) * inv_den;
+        const float alpha = fast_exp(s - mh) * inv_den;
         float ms = 1.0f;
         if (drop) {
           const uint64_t idx = (uint64_t)e * (uint64_t)a.H + (uint64_t)h;
@@ -255,8 +287,10 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
     }
   }
 
+  if (!SPLIT) {
 #pragma unroll
-  for (int o = LPR; o < kWave; o <<= 1) dq = add4(dq, shfl_xor4(dq, o));
+    for (int o = LPR; o < kWave; o <<= 1) dq = add4(dq, shfl_xor4(dq, o));
+  }
 
   if (WPN > 1) {
     if (sub == 0) *reinterpret_cast<float4*>(smem + (wave * LPR + c) * 4) = dq;
@@ -265,58 +299,79 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
 #pragma unroll
     for (int w = 1; w < WPN; ++w) dq = add4(dq, *reinterpret_cast<const float4*>(smem + ((wave + w) * LPR + c) * 4));
   }
-  if (sub == 0) {
+  if ((SPLIT || sub == 0) && row_ok) {
     scale4(dq, a.scale_inv);
     *reinterpret_cast<float4*>(a.dq + (int64_t)n * D + 4 * c) = dq;
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL>
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
 int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
   constexpr int NPB = 4 / WPN;
-  const unsigned grid = (unsigned)((a.N + NPB - 1) / NPB);
+  constexpr int RPW = SPLIT ? kWave / (D / 4) : 1;
+  const unsigned grid = (unsigned)((a.N + NPB * RPW - 1) / (NPB * RPW));
+  if (a.ev_start != nullptr) {
+    // the kernel's argument block does not need the host-side event handles
+    SegAttnArgs k = a;
+    k.ev_start = nullptr;
+    k.ev_stop = nullptr;
+    if (backward)
+      hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream,
+                            a.ev_start, a.ev_stop, 0, k);
+    else
+      hipExtLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream,
+                            a.ev_start, a.ev_stop, 0, k);
+    return 0;
+  }
   if (backward)
-    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream, a);
   return 0;
 }
 
+// mode 0: short rows (one row per lane slot), 1: one wave per row, 2: four waves per row
 template <int D, int LPH>
-int launch_dl(bool backward, bool long_rows, bool global, const SegAttnArgs& a, hipStream_t stream) {
+int launch_dl(bool backward, int mode, bool global, const SegAttnArgs& a, hipStream_t stream) {
   if constexpr (LPH <= D / 4) {
-    if (long_rows) {
-      return global ? launch_one<D, LPH, 4, true>(backward, a, stream)
-                    : launch_one<D, LPH, 4, false>(backward, a, stream);
+    if (mode == 2) {
+      return global ? launch_one<D, LPH, 4, true, false>(backward, a, stream)
+                    : launch_one<D, LPH, 4, false, false>(backward, a, stream);
     }
-    return global ? launch_one<D, LPH, 1, true>(backward, a, stream)
-                  : launch_one<D, LPH, 1, false>(backward, a, stream);
+    if (mode == 0 && D < 256) {
+      return global ? launch_one<D, LPH, 1, true, true>(backward, a, stream)
+                    : launch_one<D, LPH, 1, false, true>(backward, a, stream);
+    }
+    return global ? launch_one<D, LPH, 1, true, false>(backward, a, stream)
+                  : launch_one<D, LPH, 1, false, false>(backward, a, stream);
   } else {
     return -1;
   }
 }
 
 template <int D>
-int launch_d(int lph, bool backward, bool long_rows, bool global, const SegAttnArgs& a, hipStream_t stream) {
+int launch_d(int lph, bool backward, int mode, bool global, const SegAttnArgs& a, hipStream_t stream) {
   switch (lph) {
-    case 1: return launch_dl<D, 1>(backward, long_rows, global, a, stream);
-    case 2: return launch_dl<D, 2>(backward, long_rows, global, a, stream);
-    case 4: return launch_dl<D, 4>(backward, long_rows, global, a, stream);
-    case 8: return launch_dl<D, 8>(backward, long_rows, global, a, stream);
+    case 1: return launch_dl<D, 1>(backward, mode, global, a, stream);
+    case 2: return launch_dl<D, 2>(backward, mode, global, a, stream);
+    case 4: return launch_dl<D, 4>(backward, mode, global, a, stream);
+    case 8: return launch_dl<D, 8>(backward, mode, global, a, stream);
     default: return -1;
   }
 }
 
 int dispatch(int D, int H, bool backward, int64_t E, bool global, const SegAttnArgs& a, hipStream_t stream) {
   const int lph = D / (4 * H);
-  // long rows: split one target row over the 4 waves of a block
-  const bool long_rows = a.N > 0 && (E / a.N) >= 48;
+  // by average row length: rows shorter than two unrolled passes of a lane slot go one per slot,
+  // long rows are split over the 4 waves of a block
+  const int64_t avg = a.N > 0 ? E / a.N : 0;
+  const int mode = avg >= 48 ? 2 : (avg < 8 ? 0 : 1);
   switch (D) {
-    case 16: return launch_d<16>(lph, backward, long_rows, global, a, stream);
-    case 32: return launch_d<32>(lph, backward, long_rows, global, a, stream);
-    case 64: return launch_d<64>(lph, backward, long_rows, global, a, stream);
-    case 128: return launch_d<128>(lph, backward, long_rows, global, a, stream);
-    case 256: return launch_d<256>(lph, backward, long_rows, global, a, stream);
+    case 16: return launch_d<16>(lph, backward, mode, global, a, stream);
+    case 32: return launch_d<32>(lph, backward, mode, global, a, stream);
+    case 64: return launch_d<64>(lph, backward, mode, global, a, stream);
+    case 128: return launch_d<128>(lph, backward, mode, global, a, stream);
+    case 256: return launch_d<256>(lph, backward, mode, global, a, stream);
     default: return -1;
   }
 }
@@ -344,12 +399,13 @@ int check_shape(const char* what, int32_t N, int64_t E, int32_t D, int32_t H, in
 
 using namespace hivt;
 
-extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride,
-                                 const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
-                                 const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, float* out, float* m_out, float* den_out, int dtype,
-                                 hivt_stream_t stream) {
+static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+                             const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
+                             int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
+                             float* m_out, float* den_out, int dtype, hivt_stream_t stream, void* ev_start,
+                             void* ev_stop) {
   const char* what = "hivt_seg_attn_fwd";
+  HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
   if (rc != HIVT_OK) return rc;
   if (N == 0) return HIVT_OK;
@@ -365,19 +421,40 @@ extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v,
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
   a.dropout_p = dropout_p; a.seed = seed;
   a.out = out; a.m = m_out; a.den = den_out;
+  a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, false, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d", what, D, H);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
 
-extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v,
-                                 int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
-                                 const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
-                                 const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, float* dq, float* dk, float* dv, int64_t dkv_stride, int dtype,
+extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride,
+                                 const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
+                                 const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                                 uint64_t seed, float* out, float* m_out, float* den_out, int dtype,
                                  hivt_stream_t stream) {
+  return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
+                           out, m_out, den_out, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride,
+                                       const float* k_node, const float* v_node, int64_t node_stride,
+                                       const int32_t* src, const int32_t* rowptr, int32_t N, int64_t E, int32_t D,
+                                       int32_t H, float dropout_p, uint64_t seed, float* out, float* m_out,
+                                       float* den_out, int dtype, hivt_stream_t stream, void* start_event,
+                                       void* stop_event) {
+  return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
+                           out, m_out, den_out, dtype, stream, start_event, stop_event);
+}
+
+static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+                             const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
+                             const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
+                             int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
+                             float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream, void* ev_start,
+                             void* ev_stop) {
   const char* what = "hivt_seg_attn_bwd";
+  HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
   if (rc != HIVT_OK) return rc;
   if (N == 0) return HIVT_OK;
@@ -396,8 +473,30 @@ extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float
   a.dropout_p = dropout_p; a.seed = seed;
   a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);
   a.d_out = d_out; a.dq = dq; a.dk = dk; a.dv = dv; a.dkv_stride = dkv_stride;
+  a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, true, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d", what, D, H);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v,
+                                 int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
+                                 const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
+                                 const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                                 uint64_t seed, float* dq, float* dk, float* dv, int64_t dkv_stride, int dtype,
+                                 hivt_stream_t stream) {
+  return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
+                           H, dropout_p, seed, dq, dk, dv, dkv_stride, dtype, stream, nullptr, nullptr);
+}
+
+extern "C" int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v,
+                                       int64_t kv_stride, const float* k_node, const float* v_node,
+                                       int64_t node_stride, const int32_t* src, const int32_t* rowptr,
+                                       const float* out, const float* m, const float* den, int32_t N, int64_t E,
+                                       int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
+                                       float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream,
+                                       void* start_event, void* stop_event) {
+  return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
+                           H, dropout_p, seed, dq, dk, dv, dkv_stride, dtype, stream, start_event, stop_event);
 }

@@ -239,11 +239,12 @@ def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
     if rec is None:
         _lib.call(name, *args)
         return
+    stream = torch.cuda.current_stream(dev)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record(torch.cuda.current_stream(dev))
-    _lib.call(name, *args)
-    ev1.record(torch.cuda.current_stream(dev))
+    ev0.record(stream)  # creates the underlying events; the timed launch re-records them with the
+    ev1.record(stream)  # kernel's own start / stop time stamps
+    _lib.call(name + "_timed", *args, ctypes.c_void_p(ev0.cuda_event), ctypes.c_void_p(ev1.cuda_event))
     rec.append((kind, tag, n, e, d_model, heads, node_terms, ev0, ev1))
 
 

@@ -140,6 +140,22 @@ int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const 
                       int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
                       float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream);
 
+/* hivt_seg_attn_fwd / _bwd with in-application timing: identical computation; additionally the
+ * launch records the kernel's own start and stop time stamps into the two hipEvent_t handles
+ * (created by the caller with timing enabled), so a step can price this kernel without the
+ * dispatch gaps that events recorded around a launch include.  No counterpart in the reference. */
+int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+                            const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
+                            int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
+                            float* m_out, float* den_out, int dtype, hivt_stream_t stream, void* start_event,
+                            void* stop_event);
+int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+                            const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
+                            const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
+                            int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
+                            float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream, void* start_event,
+                            void* stop_event);
+
 /* out[r, 0:width] = sum_{i in rowptr[r]..rowptr[r+1]} rows[perm[i], 0:width] in ascending i
  * (deterministic scatter-add without atomics; perm == NULL reads rows[i]).  Used for the
  * gradient of x_j lifts (index_select backward), e.g. lin_k_node / lin_v_node outputs
