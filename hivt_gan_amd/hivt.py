@@ -139,10 +139,10 @@ class HiVT(nn.Module):
             for group, opt in (("critic", opt_d), ("generator", opt_g)):
                 if opt is None or (group == "critic" and not self.use_gan):
                     continue
-                opt.zero_grad(set_to_none=False)
                 if sync_grads is not None:
                     # the other ranks step with the averaged gradient; so must this one, or the
                     # replicas drift apart.  Without data parallelism a skipped batch changes nothing.
+                    opt.zero_grad(set_to_none=False)
                     sync_grads(group)
                     opt.step()
             return {"skipped": torch.ones((), device=data["y"].device)}
@@ -157,7 +157,7 @@ class HiVT(nn.Module):
 
         if not self.use_gan:  # Case A, models/hivt.py:270-285 (gradient clipping is the caller's business)
             loss = reg_loss + cls_loss
-            opt_g.zero_grad(set_to_none=False)
+            opt_g.zero_grad(set_to_none=True)
             loss.backward()
             if sync_grads is not None:
                 sync_grads("generator")
@@ -169,7 +169,7 @@ class HiVT(nn.Module):
         critic_params = self.critic_parameters()
         for _ in range(self.critic_steps):  # models/hivt.py:305-314
             d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
-            opt_d.zero_grad(set_to_none=False)
+            opt_d.zero_grad(set_to_none=True)
             d_loss.backward()
             if sync_grads is not None:
                 sync_grads("critic")
@@ -181,7 +181,7 @@ class HiVT(nn.Module):
         try:
             g_adv, g_logs = self.g_loss_fn.forward_masked(self.critics, fake, keep)
             g_total = reg_loss + cls_loss + g_adv
-            opt_g.zero_grad(set_to_none=False)
+            opt_g.zero_grad(set_to_none=True)
             g_total.backward()
         finally:
             for p in critic_params:

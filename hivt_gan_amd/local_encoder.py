@@ -242,20 +242,31 @@ class TemporalEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
 
     def _sa_block(self, x: torch.Tensor) -> torch.Tensor:
-        # causal self-attention over the time axis through the fused SDPA kernel; x is [S, N, D]
+        # causal self-attention over the time axis; x is [S, N, D]
         mha = self.self_attn
         S, N, D = x.shape
         H = mha.num_heads
+        if x.is_cuda and ops.temporal_attention_supported(S, D, H):
+            qkv = ops.fused_linear(x, mha.in_proj_weight, mha.in_proj_bias)
+            o = ops.temporal_attention(qkv, H, mha.dropout, self.training)
+            return self.dropout1(ops.fused_linear(o, mha.out_proj.weight, mha.out_proj.bias))
+        # stock path (CPU tensors, unsupported shapes): fused SDPA kernel of the framework
         qkv = F.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(S, N, 3, H, D // H)
         q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))  # [N, H, S, d]
         o = F.scaled_dot_product_attention(q, k, v, dropout_p=mha.dropout if self.training else 0.0, is_causal=True)
         o = o.permute(2, 0, 1, 3).reshape(S, N, D)
         return self.dropout1(mha.out_proj(o))
 
+    def _ff(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda:
+            h = ops.fused_linear(x, self.linear1.weight, self.linear1.bias, relu=True)
+            return ops.fused_linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
+        return self.linear2(self.dropout(F.relu(self.linear1(x))))
+
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
         x = src + self._sa_block(self.norm1(src))
-        return x + self.dropout2(self.linear2(self.dropout(F.relu(self.linear1(self.norm2(x))))))
+        return x + self.dropout2(self._ff(self.norm2(x)))
 
 
 class _EncoderStack(nn.Module):

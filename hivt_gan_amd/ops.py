@@ -521,3 +521,47 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0
     return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps)
+
+
+# --------------------------------------------------------------------------------------------
+# Temporal encoder attention core
+# --------------------------------------------------------------------------------------------
+class _TemporalAttn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads, dropout_p, seed):
+        _need_gpu(qkv)
+        s_len, n, three_d = qkv.shape
+        d_model = three_d // 3
+        qkv = qkv.contiguous()
+        out = torch.empty(s_len, n, d_model, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(n, num_heads, s_len, dtype=torch.float32, device=qkv.device)
+        _lib.call("hivt_temporal_attn_fwd", _p(qkv), s_len, n, d_model, num_heads, float(dropout_p), int(seed), _p(out),
+                  _p(lse), _stream(qkv))
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (int(num_heads), float(dropout_p), int(seed))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        qkv, out, lse = ctx.saved_tensors
+        num_heads, dropout_p, seed = ctx.cfg
+        s_len, n, three_d = qkv.shape
+        d_out = d_out.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        _lib.call("hivt_temporal_attn_bwd", _p(d_out), _p(qkv), _p(out), _p(lse), s_len, n, three_d // 3, num_heads,
+                  dropout_p, seed, _p(d_qkv), _stream(qkv))
+        return d_qkv, None, None, None
+
+
+def temporal_attention(qkv: torch.Tensor, num_heads: int, dropout_p: float = 0.0, training: bool = False
+                       ) -> torch.Tensor:
+    """Causal self-attention over dim 0 of the fused projection ``qkv`` [S, N, 3D] -> [S, N, D]."""
+    p = float(dropout_p) if training else 0.0
+    return _TemporalAttn.apply(qkv, int(num_heads), p, _fresh_seed() if p > 0.0 else 0)
+
+
+def temporal_attention_supported(seq_len: int, d_model: int, num_heads: int) -> bool:
+    return seq_len <= 32 and (d_model, d_model // num_heads) in ((128, 16), (64, 8), (32, 4), (16, 8), (256, 32)) \
+        and (num_heads * 32 <= 256 or (num_heads * 32) % 256 == 0)

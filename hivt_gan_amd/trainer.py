@@ -6,9 +6,9 @@ The reference wraps the whole LightningModule in DDP with ``find_unused_paramete
 backwards of a GAN step.  Here the critic gradients (1.5 MB) are reduced after the critic
 backward and the generator gradients (10.2 MB at embed_dim 128) after the generator backward; the
 critic gradients produced by the generator backward are discarded by the reference anyway
-(``models/hivt.py:312``).  The payloads are latency-bound on xGMI, so each group is ONE
-contiguous fp32 buffer that the parameters' ``.grad`` tensors alias (no packing copies), reduced
-with a single RCCL all-reduce (backend name "nccl" on ROCm).
+(``models/hivt.py:312``).  The payloads are latency-bound on xGMI, so each group is packed by ONE
+concatenation into a contiguous fp32 buffer, reduced with a single RCCL all-reduce (backend name
+"nccl" on ROCm), and handed back to the parameters as views of that buffer.
 """
 from __future__ import annotations
 
@@ -21,32 +21,39 @@ from .hivt import HiVT
 
 
 class FlatGradBucket:
-    """All ``.grad`` tensors of a parameter group as views into one contiguous buffer."""
+    """Gradients of a parameter group packed into one contiguous buffer for one all-reduce.
+
+    After a backward the group's gradients are gathered with a single concatenation (parameters
+    without a gradient contribute zeros), reduced, and handed back to the parameters as views of the
+    reduced buffer, so the optimizer reads the averaged values without further copies."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.sizes = [p.numel() for p in self.params]
+        self.flat: Optional[torch.Tensor] = None
+        self._zeros = {}
 
-    def rebind(self) -> None:
-        """Re-alias after something replaced a ``.grad`` (e.g. ``zero_grad(set_to_none=True)``)."""
+    def _zero_like(self, p: torch.nn.Parameter) -> torch.Tensor:
+        key = (p.numel(), p.device, p.dtype)
+        if key not in self._zeros:
+            self._zeros[key] = torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
+        return self._zeros[key]
+
+    def pack(self) -> torch.Tensor:
+        self.flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else self._zero_like(p) for p in self.params])
+        return self.flat
+
+    def unpack(self) -> None:
         off = 0
-        for p in self.params:
-            view = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
-            off += p.numel()
+        for p, n in zip(self.params, self.sizes):
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
 
     def all_reduce_mean(self, group=None) -> None:
+        self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(dist.get_world_size(group))
+        self.unpack()
 
 
 class GanTrainer:
@@ -74,9 +81,7 @@ class GanTrainer:
             dist.broadcast(t.data, src=0)
 
     def _sync(self, group: str) -> None:
-        bucket = self.buckets[group]
-        bucket.rebind()
-        bucket.all_reduce_mean()
+        self.buckets[group].all_reduce_mean()
 
     def step(self, data) -> Dict[str, torch.Tensor]:
         return self.model.training_step(data, self.opt_g, self.opt_d, self._sync if self.distributed else None)

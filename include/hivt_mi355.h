@@ -229,6 +229,24 @@ int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, co
                 hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Temporal encoder attention core (next-row component: TemporalEncoder)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Causal multi-head self-attention over the time axis for all agents:
+ *   out[s,n,h,:] = sum_{j<=s} drop(softmax_j(q[s,n,h,:].k[j,n,h,:] / sqrt(D/H))) v[j,n,h,:]
+ * for the fused projection qkv float [S,N,3D] (q | k | v, each D wide, head h at columns h*D/H..),
+ * S <= 32.  Replaces the attention inside nn.MultiheadAttention(x, x, x, attn_mask=causal) of
+ * TemporalEncoderLayer._sa_block (models/local_encoder.py:271-276, mask :237-241) including its
+ * dropout on the attention weights.  Saves lse float [N,H,S] for the backward. */
+int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p,
+                           uint64_t seed, float* out, float* lse, hivt_stream_t stream);
+
+/* Backward of the above: d_qkv float [S,N,3D] from d_out [S,N,D], the forward inputs / outputs. */
+int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse, int32_t S,
+                           int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* d_qkv,
+                           hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused regression / classification loss (min over modes + Laplace NLL + soft-target CE)
  * ------------------------------------------------------------------------------------------ */
 

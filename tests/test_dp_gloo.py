@@ -135,15 +135,16 @@ def test_two_rank_step_matches_manual_average(tmp_path, poison_rank):
         assert torch.allclose(dp[group], ref[group], rtol=1e-5, atol=1e-7), f"{group} gradients differ"
 
 
-def test_flat_bucket_aliases_gradients():
+def test_flat_bucket_packs_and_hands_back_views():
     lin = torch.nn.Linear(3, 2)
+    extra = torch.nn.Parameter(torch.zeros(5))  # never receives a gradient
     from hivt_gan_amd.trainer import FlatGradBucket
-    bucket = FlatGradBucket(lin.parameters())
+    bucket = FlatGradBucket(list(lin.parameters()) + [extra])
     lin(torch.ones(4, 3)).sum().backward()
-    assert bucket.flat.abs().sum() > 0
-    assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
-    torch.optim.SGD(lin.parameters(), lr=0.1).zero_grad(set_to_none=True)
-    lin(torch.ones(4, 3)).sum().backward()
-    bucket.rebind()
-    assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
-    assert torch.equal(bucket.flat[:6].view(2, 3), torch.full((2, 3), 4.0))
+    flat = bucket.pack()
+    assert flat.shape == (6 + 2 + 5,)
+    assert torch.equal(flat[:6].view(2, 3), torch.full((2, 3), 4.0)) and torch.all(flat[8:] == 0)
+    flat.mul_(0.5)
+    bucket.unpack()
+    assert lin.weight.grad.data_ptr() == flat.data_ptr()
+    assert torch.equal(lin.weight.grad, torch.full((2, 3), 2.0)) and torch.all(extra.grad == 0)

@@ -417,3 +417,47 @@ def test_fused_linear_strided_input_and_3d():
     y3 = ops.fused_linear(x3.to(DEV), w3.to(DEV), None, relu=True)
     assert y3.shape == (20, 33, 64)
     close(y3, torch.relu(torch.nn.functional.linear(x3, w3)))
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal encoder attention core
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,N,D,H", [(21, 37, 128, 8), (21, 50, 64, 8), (5, 9, 16, 2), (32, 3, 64, 8), (1, 4, 128, 8)])
+def test_temporal_attention_vs_oracle(S, N, D, H):
+    gen = torch.Generator().manual_seed(S * N)
+    qkv = torch.randn(S, N, 3 * D, generator=gen)
+    w = torch.randn(S, N, D, generator=gen)
+
+    def ref(dtype):
+        t = qkv.to(dtype).clone().requires_grad_(True)
+        d = D // H
+        q, k, v = (t[..., i * D:(i + 1) * D].reshape(S, N * H, d).transpose(0, 1) for i in range(3))
+        mask = torch.triu(torch.full((S, S), float("-inf"), dtype=dtype), diagonal=1)
+        p = torch.softmax(torch.baddbmm(mask, q / d ** 0.5, k.transpose(-2, -1)), dim=-1)
+        o = torch.bmm(p, v).transpose(0, 1).reshape(S, N, D)
+        (o * w.to(dtype)).sum().backward()
+        return o, t.grad
+
+    o32, g32 = ref(torch.float32)
+    o64, g64 = ref(torch.float64)
+    tg = qkv.to(DEV).requires_grad_(True)
+    o = ops.temporal_attention(tg, H)
+    (o * w.to(DEV)).sum().backward()
+    close64(o, o32, o64, msg="out")
+    close64(tg.grad, g32, g64, msg="d_qkv")
+
+
+def test_temporal_attention_dropout_mask_consistency():
+    S, N, D, H, p = 21, 200, 128, 8, 0.2
+    qkv = torch.zeros(S, N, 3 * D, device=DEV)
+    qkv[..., 2 * D:] = 1.0  # uniform attention over the causal prefix, V == 1
+    qkv.requires_grad_(True)
+    torch.manual_seed(3)
+    o = ops.temporal_attention(qkv, H, dropout_p=p, training=True)
+    # row i averages i+1 kept/dropped weights scaled by 1/(1-p): mean 1
+    assert abs(o.mean().item() - 1.0) < 0.01
+    assert o[0].unique().numel() == 2  # first step has a single key: either dropped (0) or 1/(1-p)
+    o.sum().backward()
+    assert torch.isfinite(qkv.grad).all()
+    assert torch.allclose(ops.temporal_attention(qkv.detach(), H, dropout_p=p, training=False),
+                          torch.ones(S, N, D, device=DEV), atol=1e-6)
