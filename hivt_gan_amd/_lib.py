@@ -23,19 +23,19 @@ SIGNATURES = {
                                     c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_edges_radius": (c_int, [_P, c_int64, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hivt_csr_build": (c_int, [_P, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
-    "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
-    "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P]),
-    "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "hivt_csr_build": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
+    "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
+    "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
     "hivt_seg_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32, c_int32,
-                                  c_float, c_uint64, _P, _P, _P, c_int, _P]),
+                                  c_float, c_uint64, _P, _P, _P, _P, c_int, _P]),
     "hivt_seg_attn_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64,
-                                  c_int32, c_int32, c_float, c_uint64, _P, _P, _P, c_int64, c_int, _P]),
+                                  c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int64, c_int32, c_int, _P]),
     "hivt_seg_attn_fwd_timed": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32,
-                                        c_int32, c_float, c_uint64, _P, _P, _P, c_int, _P, _P, _P]),
+                                        c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32,
-                                        c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, c_int64, c_int, _P,
-                                        _P, _P]),
+                                        c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int64,
+                                        c_int32, c_int, _P, _P, _P]),
     "hivt_segment_sum_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
     "hivt_gated_update_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P]),
     "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,
@@ -48,8 +48,8 @@ SIGNATURES = {
     "hivt_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_ln_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_int64, c_int32, _P, c_int64, _P, _P, _P,
                             c_size_t, _P]),
-    "hivt_temporal_attn_fwd": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P, _P]),
-    "hivt_temporal_attn_bwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P,
+    "hivt_temporal_attn_fwd": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P]),
+    "hivt_temporal_attn_bwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P,
                                        _P]),
     "hivt_laplace_workspace_bytes": (c_size_t, [c_int32]),
     "hivt_laplace_minmode_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P,

@@ -188,17 +188,27 @@ int run_filter(const Pred& pred, int64_t items, int32_t* src_out, int32_t* dst_o
 }
 
 // ---- CSR build ------------------------------------------------------------------------------
-__global__ void csr_hist_kernel(const int32_t* __restrict__ key, int64_t E, int32_t* __restrict__ deg) {
+// `count` (optional, device memory) holds the number of meaningful entries when the list is padded
+// to a fixed capacity E; entries at or beyond it are ignored.
+__device__ __forceinline__ int64_t live_entries(int64_t E, const int32_t* count) {
+  if (count == nullptr) return E;
+  const int64_t c = *count;
+  return c < E ? (c < 0 ? 0 : c) : E;
+}
+
+__global__ void csr_hist_kernel(const int32_t* __restrict__ key, int64_t E, const int32_t* __restrict__ count,
+                                int32_t* __restrict__ deg) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < E) atomicAdd(&deg[key[i]], 1);
+  if (i < live_entries(E, count)) atomicAdd(&deg[key[i]], 1);
 }
 
 // Unordered placement: slot = rowptr[key] + arrival ticket.  The order inside a row is fixed
 // afterwards by csr_row_sort_kernel, so the result does not depend on atomic arrival order.
-__global__ void csr_place_kernel(const int32_t* __restrict__ key, int64_t E, const int32_t* __restrict__ rowptr,
-                                 int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
+__global__ void csr_place_kernel(const int32_t* __restrict__ key, int64_t E, const int32_t* __restrict__ count,
+                                 const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursor,
+                                 int32_t* __restrict__ tmp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < E) {
+  if (i < live_entries(E, count)) {
     const int32_t k = key[i];
     const int32_t slot = rowptr[k] + atomicAdd(&cursor[k], 1);
     tmp[slot] = (int32_t)i;
@@ -304,8 +314,9 @@ extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {
          align_up((size_t)(E > 0 ? E : 1) * sizeof(int32_t), 256);
 }
 
-extern "C" int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, int32_t* rowptr, int32_t* perm,
-                              void* workspace, size_t workspace_bytes, hivt_stream_t stream_) {
+extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
+                              int32_t* rowptr, int32_t* perm, void* workspace, size_t workspace_bytes,
+                              hivt_stream_t stream_) {
   const char* what = "hivt_csr_build";
   hipStream_t stream = (hipStream_t)stream_;
   HIVT_REQUIRE(E >= 0 && E < (int64_t)1 << 31 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
@@ -319,7 +330,8 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, i
   // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
   HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), stream), what);
   if (E > 0) {
-    hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, cursor);
+    hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, count,
+                       cursor);
     HIVT_CHECK_LAUNCH(what);
   }
   hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, cursor, (int64_t)num_rows, rowptr,
@@ -327,8 +339,8 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, i
   HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
     HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)num_rows * sizeof(int32_t), stream), what);
-    hipLaunchKernelGGL(csr_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, rowptr,
-                       cursor, tmp);
+    hipLaunchKernelGGL(csr_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, count,
+                       rowptr, cursor, tmp);
     HIVT_CHECK_LAUNCH(what);
     hipLaunchKernelGGL(csr_row_sort_kernel, dim3((unsigned)((num_rows + 3) / 4)), dim3(256), 0, stream, rowptr, tmp,
                        num_rows, perm);

@@ -12,10 +12,16 @@ namespace {
 __global__ __launch_bounds__(256) void gather_rotate_fwd_kernel(
     const float* __restrict__ x_src, int64_t x_stride, const float* __restrict__ attr,
     const float* __restrict__ rot, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-    const int32_t* __restrict__ perm, int32_t rot_mod, int64_t E, float* __restrict__ out,
-    int32_t* __restrict__ src_csr, int32_t* __restrict__ dst_csr) {
+    const int32_t* __restrict__ perm, int32_t rot_mod, int64_t E, const int32_t* __restrict__ count,
+    float* __restrict__ out, int32_t* __restrict__ src_csr, int32_t* __restrict__ dst_csr) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
+  if (count != nullptr && e >= *count) {  // padding row of a fixed-capacity list: inert record
+    *reinterpret_cast<float4*>(out + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src_csr) src_csr[e] = 0;
+    if (dst_csr) dst_csr[e] = 0;
+    return;
+  }
   const int64_t p = perm ? perm[e] : e;
   const int32_t s = src[p], d = dst[p];
   const float2 xs = *reinterpret_cast<const float2*>(x_src + (int64_t)s * x_stride);
@@ -39,9 +45,9 @@ __global__ __launch_bounds__(256) void gather_rotate_fwd_kernel(
 __global__ __launch_bounds__(256) void gather_rotate_bwd_kernel(
     const float* __restrict__ d_out, const float* __restrict__ rot, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, const int32_t* __restrict__ perm, int32_t rot_mod, int64_t E,
-    float* __restrict__ d_attr, float* __restrict__ d_x) {
+    const int32_t* __restrict__ count, float* __restrict__ d_attr, float* __restrict__ d_x) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+  if (e >= E || (count != nullptr && e >= *count)) return;
   const int64_t p = perm ? perm[e] : e;
   const float4 g = *reinterpret_cast<const float4*>(d_out + 4 * e);
   float2 gx = make_float2(g.x, g.y), ga = make_float2(g.z, g.w);
@@ -64,10 +70,17 @@ __global__ __launch_bounds__(256) void relpose_fwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ src,
                                                           const int32_t* __restrict__ dst,
                                                           const int32_t* __restrict__ perm, int64_t E,
+                                                          const int32_t* __restrict__ count,
                                                           float* __restrict__ out, int32_t* __restrict__ src_csr,
                                                           int32_t* __restrict__ dst_csr) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
+  if (count != nullptr && e >= *count) {
+    *reinterpret_cast<float4*>(out + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src_csr) src_csr[e] = 0;
+    if (dst_csr) dst_csr[e] = 0;
+    return;
+  }
   const int64_t p = perm ? perm[e] : e;
   const int32_t s = src[p], d = dst[p];
   const float2 a = *reinterpret_cast<const float2*>(attr + 2 * p);
@@ -90,8 +103,8 @@ using namespace hivt;
 
 extern "C" int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride, const float* attr, const float* rot,
                                            const int32_t* src, const int32_t* dst, const int32_t* perm,
-                                           int32_t rot_mod, int64_t E, float* out, int32_t* src_csr,
-                                           int32_t* dst_csr, hivt_stream_t stream) {
+                                           int32_t rot_mod, int64_t E, const int32_t* count, float* out,
+                                           int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream) {
   const char* what = "hivt_edge_gather_rotate_fwd";
   HIVT_REQUIRE(E >= 0, HIVT_ERR_ARG, "%s: negative edge count", what);
   if (E == 0) return HIVT_OK;
@@ -99,34 +112,35 @@ extern "C" int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride,
   HIVT_REQUIRE(x_stride >= 2 && x_stride % 2 == 0, HIVT_ERR_ARG, "%s: x_stride must be even and >= 2", what);
   HIVT_REQUIRE(rot == nullptr || rot_mod > 0, HIVT_ERR_ARG, "%s: rot_mod must be positive", what);
   hipLaunchKernelGGL(gather_rotate_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     x_src, x_stride, attr, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, out, src_csr, dst_csr);
+                     x_src, x_stride, attr, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, count, out, src_csr,
+                     dst_csr);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
 
 extern "C" int hivt_edge_gather_rotate_bwd(const float* d_out, const float* rot, const int32_t* src,
                                            const int32_t* dst, const int32_t* perm, int32_t rot_mod, int64_t E,
-                                           float* d_attr, float* d_x, hivt_stream_t stream) {
+                                           const int32_t* count, float* d_attr, float* d_x, hivt_stream_t stream) {
   const char* what = "hivt_edge_gather_rotate_bwd";
   HIVT_REQUIRE(E >= 0, HIVT_ERR_ARG, "%s: negative edge count", what);
   if (E == 0 || (d_attr == nullptr && d_x == nullptr)) return HIVT_OK;
   HIVT_REQUIRE(d_out && src && dst, HIVT_ERR_ARG, "%s: null pointer", what);
   HIVT_REQUIRE(rot == nullptr || rot_mod > 0, HIVT_ERR_ARG, "%s: rot_mod must be positive", what);
   hipLaunchKernelGGL(gather_rotate_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     d_out, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, d_attr, d_x);
+                     d_out, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, count, d_attr, d_x);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
 
 extern "C" int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angles, const int32_t* src,
-                                     const int32_t* dst, const int32_t* perm, int64_t E, float* out,
-                                     int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream) {
+                                     const int32_t* dst, const int32_t* perm, int64_t E, const int32_t* count,
+                                     float* out, int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream) {
   const char* what = "hivt_edge_relpose_fwd";
   HIVT_REQUIRE(E >= 0, HIVT_ERR_ARG, "%s: negative edge count", what);
   if (E == 0) return HIVT_OK;
   HIVT_REQUIRE(attr && rot && angles && src && dst && out, HIVT_ERR_ARG, "%s: null pointer", what);
   hipLaunchKernelGGL(relpose_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, attr,
-                     rot, angles, src, dst, perm, E, out, src_csr, dst_csr);
+                     rot, angles, src, dst, perm, E, count, out, src_csr, dst_csr);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

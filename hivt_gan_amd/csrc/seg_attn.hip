@@ -35,6 +35,7 @@ struct SegAttnArgs {
   float scale_inv;
   float dropout_p;
   uint64_t seed;
+  const uint64_t* seed_ptr;  // optional device-side seed added to `seed` (graph replays vary it)
   // forward outputs / backward saved
   float* out;
   float* m;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   }
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
 
   float m = kNegSentinel, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
       l += p;
       if (drop) {
         const uint64_t idx = (uint64_t)(e0 + u * STRIDE) * (uint64_t)a.H + (uint64_t)h;
-        p = uniform01(a.seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
+        p = uniform01(seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
       }
       fma4(acc, p, vv[u]);
     }
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   }
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
 
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
         float ms = 1.0f;
         if (drop) {
           const uint64_t idx = (uint64_t)e * (uint64_t)a.H + (uint64_t)h;
-          ms = uniform01(a.seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
+          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
         }
         const float am = alpha * ms;
         const float ds = alpha * (dav * ms - delta);
@@ -302,6 +305,22 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   if ((SPLIT || sub == 0) && row_ok) {
     scale4(dq, a.scale_inv);
     *reinterpret_cast<float4*>(a.dq + (int64_t)n * D + 4 * c) = dq;
+  }
+}
+
+// Rows [rowptr[N], E_cap) of dk / dv belong to no target (fixed-capacity edge lists): zero them so
+// that everything upstream of the projection sees exact zeros for the padding.
+__global__ __launch_bounds__(256) void zero_tail_kernel(const int32_t* __restrict__ rowptr, int32_t N, int64_t E_cap,
+                                                        int32_t D, float* __restrict__ dk, float* __restrict__ dv,
+                                                        int64_t stride) {
+  const int64_t live = rowptr[N];
+  const int64_t quads = D / 4;
+  const int64_t total = (E_cap - live) * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = live + i / quads;
+    const int c = (int)(i % quads) * 4;
+    *reinterpret_cast<float4*>(dk + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dv + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -401,9 +420,9 @@ using namespace hivt;
 
 static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                              const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                             int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
-                             float* m_out, float* den_out, int dtype, hivt_stream_t stream, void* ev_start,
-                             void* ev_stop) {
+                             int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                             const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                             hivt_stream_t stream, void* ev_start, void* ev_stop) {
   const char* what = "hivt_seg_attn_fwd";
   HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
@@ -419,7 +438,7 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
-  a.dropout_p = dropout_p; a.seed = seed;
+  a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = out; a.m = m_out; a.den = den_out;
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, false, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
@@ -431,28 +450,28 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
 extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride,
                                  const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                                  const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, float* out, float* m_out, float* den_out, int dtype,
-                                 hivt_stream_t stream) {
+                                 uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out,
+                                 int dtype, hivt_stream_t stream) {
   return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
-                           out, m_out, den_out, dtype, stream, nullptr, nullptr);
+                           seed_ptr, out, m_out, den_out, dtype, stream, nullptr, nullptr);
 }
 
 extern "C" int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride,
                                        const float* k_node, const float* v_node, int64_t node_stride,
                                        const int32_t* src, const int32_t* rowptr, int32_t N, int64_t E, int32_t D,
-                                       int32_t H, float dropout_p, uint64_t seed, float* out, float* m_out,
-                                       float* den_out, int dtype, hivt_stream_t stream, void* start_event,
-                                       void* stop_event) {
+                                       int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
+                                       float* out, float* m_out, float* den_out, int dtype, hivt_stream_t stream,
+                                       void* start_event, void* stop_event) {
   return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
-                           out, m_out, den_out, dtype, stream, start_event, stop_event);
+                           seed_ptr, out, m_out, den_out, dtype, stream, start_event, stop_event);
 }
 
 static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
                              const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                              const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                             int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
-                             float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream, void* ev_start,
-                             void* ev_stop) {
+                             int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                             const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
+                             int32_t zero_tail, int dtype, hivt_stream_t stream, void* ev_start, void* ev_stop) {
   const char* what = "hivt_seg_attn_bwd";
   HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
@@ -470,13 +489,18 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
-  a.dropout_p = dropout_p; a.seed = seed;
+  a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);
   a.d_out = d_out; a.dq = dq; a.dk = dk; a.dv = dv; a.dkv_stride = dkv_stride;
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, true, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d", what, D, H);
   HIVT_CHECK_LAUNCH(what);
+  if (zero_tail && E > 0) {
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, rowptr, N, E, D, dk, dv,
+                       dkv_stride);
+    HIVT_CHECK_LAUNCH(what);
+  }
   return HIVT_OK;
 }
 
@@ -484,19 +508,22 @@ extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float
                                  int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
                                  const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
                                  const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, float* dq, float* dk, float* dv, int64_t dkv_stride, int dtype,
-                                 hivt_stream_t stream) {
+                                 uint64_t seed, const uint64_t* seed_ptr, float* dq, float* dk, float* dv,
+                                 int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream) {
   return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
-                           H, dropout_p, seed, dq, dk, dv, dkv_stride, dtype, stream, nullptr, nullptr);
+                           H, dropout_p, seed, seed_ptr, dq, dk, dv, dkv_stride, zero_tail, dtype, stream, nullptr,
+                           nullptr);
 }
 
 extern "C" int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v,
                                        int64_t kv_stride, const float* k_node, const float* v_node,
                                        int64_t node_stride, const int32_t* src, const int32_t* rowptr,
                                        const float* out, const float* m, const float* den, int32_t N, int64_t E,
-                                       int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
-                                       float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream,
-                                       void* start_event, void* stop_event) {
+                                       int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                       const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
+                                       int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event,
+                                       void* stop_event) {
   return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
-                           H, dropout_p, seed, dq, dk, dv, dkv_stride, dtype, stream, start_event, stop_event);
+                           H, dropout_p, seed, seed_ptr, dq, dk, dv, dkv_stride, zero_tail, dtype, stream,
+                           start_event, stop_event);
 }

@@ -27,6 +27,7 @@ struct TAttnArgs {
   float scale;
   float dropout_p;
   uint64_t seed;
+  const uint64_t* seed_ptr;  // optional device-side seed added to `seed`
 };
 
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void temporal_attn_fwd_kernel(const TAttnArgs 
   __syncthreads();
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
   // (head, query) pairs: H * S of them, 256 threads per pass
   for (int t = threadIdx.x; t < a.H * kMaxS; t += 256) {
     const int h = t / kMaxS, i = t % kMaxS;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void temporal_attn_fwd_kernel(const TAttnArgs 
       l = l * corr + p;
       if (drop) {
         const uint64_t idx = (((uint64_t)n * a.H + h) * kMaxS + i) * kMaxS + j;
-        p = uniform01(a.seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
+        p = uniform01(seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
       }
 #pragma unroll
       for (int x = 0; x < HD; ++x) acc[x] = acc[x] * corr + p * vr[x];
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
   __syncthreads();
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
   // Every thread owns index r of head h twice: as a QUERY (dQ_r) and as a KEY (dK_r, dV_r).
   // A pass covers 256 / kMaxS whole heads; all threads run every pass so that the barrier between
   // the last read and the in-place overwrite of a pass's q|k|v slots is reached by everyone.
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
         float ms = 1.0f;
         if (drop) {
           const uint64_t idx = (((uint64_t)n * H + h) * kMaxS + r) * kMaxS + j;
-          ms = uniform01(a.seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
+          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
         }
         const float ds = p * (dp * ms - delta_r) * a.scale;
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
         float ms = 1.0f;
         if (drop) {
           const uint64_t idx = (((uint64_t)n * H + h) * kMaxS + i) * kMaxS + r;
-          ms = uniform01(a.seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
+          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
         }
         const float ds = p * (dp * ms - aux[(h * kMaxS + i) * 2 + 1]) * a.scale;
         const float pm = p * ms;
@@ -249,7 +252,8 @@ int check(const char* what, int32_t S, int32_t N, int32_t D, int32_t H, float p)
 using namespace hivt;
 
 extern "C" int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p,
-                                      uint64_t seed, float* out, float* lse, hivt_stream_t stream) {
+                                      uint64_t seed, const uint64_t* seed_ptr, float* out, float* lse,
+                                      hivt_stream_t stream) {
   const char* what = "hivt_temporal_attn_fwd";
   int rc = check(what, S, N, D, H, dropout_p);
   if (rc != HIVT_OK) return rc;
@@ -257,7 +261,7 @@ extern "C" int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, in
   HIVT_REQUIRE(qkv && out && lse, HIVT_ERR_ARG, "%s: null pointer", what);
   TAttnArgs a{};
   a.qkv = qkv; a.out = out; a.lse = lse; a.S = S; a.N = N; a.H = H;
-  a.scale = 1.0f / sqrtf((float)(D / H)); a.dropout_p = dropout_p; a.seed = seed;
+  a.scale = 1.0f / sqrtf((float)(D / H)); a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   HIVT_REQUIRE(dispatch(D, H, false, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG, "%s: no kernel for D=%d H=%d", what,
                D, H);
   HIVT_CHECK_LAUNCH(what);
@@ -266,7 +270,7 @@ extern "C" int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, in
 
 extern "C" int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse,
                                       int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                                      float* d_qkv, hivt_stream_t stream) {
+                                      const uint64_t* seed_ptr, float* d_qkv, hivt_stream_t stream) {
   const char* what = "hivt_temporal_attn_bwd";
   int rc = check(what, S, N, D, H, dropout_p);
   if (rc != HIVT_OK) return rc;
@@ -275,7 +279,7 @@ extern "C" int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, cons
   TAttnArgs a{};
   a.qkv = qkv; a.out = const_cast<float*>(out); a.lse = const_cast<float*>(lse); a.d_out = d_out; a.d_qkv = d_qkv;
   a.S = S; a.N = N; a.H = H;
-  a.scale = 1.0f / sqrtf((float)(D / H)); a.dropout_p = dropout_p; a.seed = seed;
+  a.scale = 1.0f / sqrtf((float)(D / H)); a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   HIVT_REQUIRE(dispatch(D, H, true, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG, "%s: no kernel for D=%d H=%d", what, D,
                H);
   HIVT_CHECK_LAUNCH(what);

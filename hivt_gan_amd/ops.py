@@ -107,8 +107,10 @@ def edges_radius(edge_index: torch.Tensor, edge_attr: torch.Tensor, radius: Opti
     return src, dst, attr, count
 
 
-def csr_build(key: torch.Tensor, num_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Stable grouping of edge positions by ``key``: returns (rowptr int32 [num_rows+1], perm int32 [E])."""
+def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = None
+              ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable grouping of edge positions by ``key``: returns (rowptr int32 [num_rows+1], perm int32 [E]).
+    ``count`` (device int32 scalar) marks the live prefix of a list padded to a fixed capacity."""
     _need_gpu(key)
     if key.dtype != torch.int32 or key.dim() != 1:
         raise ValueError("key must be an int32 vector")
@@ -118,7 +120,8 @@ def csr_build(key: torch.Tensor, num_rows: int) -> Tuple[torch.Tensor, torch.Ten
     rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
     ws = _workspace(_lib.query("hivt_csr_workspace_bytes", e, num_rows), dev)
-    _lib.call("hivt_csr_build", _p(key), e, num_rows, _p(rowptr), _p(perm), _p(ws), ws.numel(), _stream(key))
+    _lib.call("hivt_csr_build", _p(key), e, _p(count), num_rows, _p(rowptr), _p(perm), _p(ws), ws.numel(),
+              _stream(key))
     return rowptr, perm
 
 
@@ -140,6 +143,7 @@ class EdgeSet:
     dst: Optional[torch.Tensor] = None
     rowptr_by_src: Optional[torch.Tensor] = None
     perm_by_src: Optional[torch.Tensor] = None
+    count: Optional[torch.Tensor] = None  # device int32: live edges when the lists are padded to a capacity
 
     @property
     def num_edges(self) -> int:
@@ -152,13 +156,14 @@ class EdgeSet:
     def group_by_source(self) -> None:
         """CSR over sources of the CSR-ordered edges (for gradients of source lifts)."""
         if self.rowptr_by_src is None:
-            self.rowptr_by_src, self.perm_by_src = csr_build(self.src, self.num_src)
+            self.rowptr_by_src, self.perm_by_src = csr_build(self.src, self.num_src, self.count)
 
 
-def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
-    """Group an already filtered int32 COO list by target."""
-    rowptr, perm = csr_build(dst, num_dst)
-    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm)
+def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_src: int, num_dst: int,
+                  count: Optional[torch.Tensor] = None) -> EdgeSet:
+    """Group an already filtered int32 COO list by target (``count``: live prefix of padded lists)."""
+    rowptr, perm = csr_build(dst, num_dst, count)
+    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm, count=count)
 
 
 # --------------------------------------------------------------------------------------------
@@ -167,7 +172,7 @@ def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_
 class _EdgeGatherRotate(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x_src, attr, rot, src, dst, perm, rot_mod):
+    def forward(ctx, x_src, attr, rot, src, dst, perm, rot_mod, count):
         _need_gpu(x_src, attr, src, dst)
         x2 = x_src if (x_src.dim() == 2 and x_src.stride(1) == 1 and x_src.stride(0) % 2 == 0
                        and x_src.data_ptr() % 8 == 0) else x_src.contiguous()
@@ -178,8 +183,8 @@ class _EdgeGatherRotate(torch.autograd.Function):
         src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
         dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
         _lib.call("hivt_edge_gather_rotate_fwd", _p(x2), x2.stride(0), _p(attr), _p(rot_c), _p(src), _p(dst), _p(perm),
-                  int(rot_mod), e, _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
-        ctx.save_for_backward(rot_c, src, dst, perm)
+                  int(rot_mod), e, _p(count), _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
+        ctx.save_for_backward(rot_c, src, dst, perm, count)
         ctx.rot_mod = int(rot_mod)
         ctx.x_shape = tuple(x_src.shape)
         ctx.mark_non_differentiable(src_csr, dst_csr)
@@ -188,31 +193,35 @@ class _EdgeGatherRotate(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out, _g1, _g2):
-        rot_c, src, dst, perm = ctx.saved_tensors
+        rot_c, src, dst, perm, count = ctx.saved_tensors
         e = src.shape[0]
         d_out = d_out.contiguous()
         d_x = torch.zeros(ctx.x_shape[0], 2, dtype=torch.float32, device=d_out.device) if ctx.needs_input_grad[0] \
             else None
-        d_attr = torch.empty(e, 2, dtype=torch.float32, device=d_out.device) if ctx.needs_input_grad[1] else None
+        d_attr = None
+        if ctx.needs_input_grad[1]:
+            d_attr = (torch.zeros if count is not None else torch.empty)(e, 2, dtype=torch.float32, device=d_out.device)
         if d_x is not None or d_attr is not None:
             _lib.call("hivt_edge_gather_rotate_bwd", _p(d_out), _p(rot_c), _p(src), _p(dst), _p(perm), ctx.rot_mod, e,
-                      _p(d_attr), _p(d_x), _stream(d_out))
+                      _p(count), _p(d_attr), _p(d_x), _stream(d_out))
         if d_x is not None and ctx.x_shape[1] != 2:
             full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=d_out.device)
             full[:, :2] = d_x
             d_x = full
-        return d_x, d_attr, None, None, None, None, None
+        return d_x, d_attr, None, None, None, None, None, None
 
 
 def edge_gather_rotate(x_src: torch.Tensor, attr: torch.Tensor, rot: Optional[torch.Tensor], src: torch.Tensor,
-                       dst: torch.Tensor, perm: Optional[torch.Tensor], rot_mod: int
-                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``[x_src[src] @ R[dst % rot_mod], attr @ R[dst % rot_mod]]`` per edge in ``perm`` order -> ([E,4], src, dst)."""
-    return _EdgeGatherRotate.apply(x_src, attr, rot, src, dst, perm, rot_mod)
+                       dst: torch.Tensor, perm: Optional[torch.Tensor], rot_mod: int,
+                       count: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``[x_src[src] @ R[dst % rot_mod], attr @ R[dst % rot_mod]]`` per edge in ``perm`` order -> ([E,4], src, dst).
+    Rows at or beyond ``count`` (padding of fixed-capacity lists) come out as zeros / index 0."""
+    return _EdgeGatherRotate.apply(x_src, attr, rot, src, dst, perm, rot_mod, count)
 
 
 def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
-                 perm: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 perm: Optional[torch.Tensor], count: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Global-interactor edge features ``[rel_pos @ R[dst], cos dtheta, sin dtheta]`` (inputs carry no grad)."""
     _need_gpu(attr, rot, angles, src, dst)
     e = src.shape[0]
@@ -220,8 +229,8 @@ def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, sr
     out = torch.empty(e, 4, dtype=torch.float32, device=attr.device)
     src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
     dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
-    _lib.call("hivt_edge_relpose_fwd", _p(attr), _p(rot), _p(angles), _p(src), _p(dst), _p(perm), e, _p(out),
-              _p(src_csr), _p(dst_csr), _stream(attr))
+    _lib.call("hivt_edge_relpose_fwd", _p(attr), _p(rot), _p(angles), _p(src), _p(dst), _p(perm), e, _p(count),
+              _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
     return out, src_csr, dst_csr
 
 
@@ -248,15 +257,31 @@ def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
     rec.append((kind, tag, n, e, d_model, heads, node_terms, ev0, ev1))
 
 
+# Dropout seeds.  Eagerly every call draws a host-side seed (CPU generator: no device sync,
+# reproducible under torch.manual_seed).  When DEVICE_SEED is set (a uint64-as-int64 device scalar
+# owned by the caller) the kernels add its current value to a per-call constant instead, so a
+# captured graph draws new masks on every replay as long as the caller advances the scalar.
+DEVICE_SEED: Optional[torch.Tensor] = None
+_seed_calls = 0
+
+
 def _fresh_seed() -> int:
-    # CPU generator: no device synchronisation, reproducible under torch.manual_seed
+    global _seed_calls
+    if DEVICE_SEED is not None:
+        _seed_calls += 1
+        return (_seed_calls * 0x9E3779B97F4A7C15) & ((1 << 62) - 1)
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _seed_ptr(dropout_p: float):
+    return _p(DEVICE_SEED) if (DEVICE_SEED is not None and dropout_p > 0.0) else None
 
 
 class _SegAttn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed, tag):
+    def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed, tag,
+                padded):
         _need_gpu(q, kv, rowptr)
         n, d_model = q.shape
         e = kv.shape[0]
@@ -278,17 +303,18 @@ class _SegAttn(torch.autograd.Function):
                     "hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                    _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _p(out), _p(m), _p(den), 0,
-                    _stream(q))
-        ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den)
-        ctx.cfg = (num_heads, float(dropout_p), int(seed), tag)
+                    _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(out),
+                    _p(m), _p(den), 0, _stream(q))
+        ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den,
+                              DEVICE_SEED if dropout_p > 0.0 else None)
+        ctx.cfg = (num_heads, float(dropout_p), int(seed), tag, bool(padded))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out):
-        q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den = ctx.saved_tensors
-        num_heads, dropout_p, seed, tag = ctx.cfg
+        q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den, seed_dev = ctx.saved_tensors
+        num_heads, dropout_p, seed, tag, padded = ctx.cfg
         n, d_model = q.shape
         e = kv.shape[0]
         d_out = d_out.contiguous()
@@ -299,31 +325,34 @@ class _SegAttn(torch.autograd.Function):
                     "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                  _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(dq), _p(dkv),
-                  _p(dkv, fb), 2 * d_model, 0, _stream(q))
+                  _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
+                  _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, 0, _stream(q))
         dkv_node = None
         if kv_node is not None and ctx.needs_input_grad[2]:
             ns = kv_node.shape[0]
             dkv_node = torch.empty(ns, 2 * d_model, dtype=torch.float32, device=q.device)
             _lib.call("hivt_segment_sum_rows", _p(dkv), 2 * d_model, 2 * d_model, _p(rowptr_by_src), _p(perm_by_src),
                       ns, _p(dkv_node), 2 * d_model, _stream(q))
-        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None
+        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None, None
 
 
 def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
              training: bool = False, kv_node: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
              rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None,
-             tag: str = "") -> torch.Tensor:
+             tag: str = "", padded: bool = False) -> torch.Tensor:
     """Segment-softmax attention over CSR rows.
 
     ``q`` [N,D]; ``kv`` [E,2D] holds K | V per edge in CSR order; optional ``kv_node`` [Ns,2D] adds the
     source node's K | V (``src`` gives the source id of every CSR-ordered edge, and the CSR over
-    sources is needed for its gradient).  Returns the aggregated messages [N,D]."""
+    sources is needed for its gradient).  ``padded`` says that ``kv`` has more rows than ``rowptr``
+    covers (fixed-capacity edge lists): the gradient rows of that padding are then zeroed.
+    Returns the aggregated messages [N,D]."""
     p = float(dropout_p) if training else 0.0
     seed = _fresh_seed() if p > 0.0 else 0
     if kv_node is not None and kv_node.requires_grad and (rowptr_by_src is None or perm_by_src is None):
         raise ValueError("gradient of the node terms needs the CSR over sources")
-    return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed, tag)
+    return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed, tag,
+                          padded)
 
 
 # --------------------------------------------------------------------------------------------
@@ -536,22 +565,22 @@ class _TemporalAttn(torch.autograd.Function):
         qkv = qkv.contiguous()
         out = torch.empty(s_len, n, d_model, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(n, num_heads, s_len, dtype=torch.float32, device=qkv.device)
-        _lib.call("hivt_temporal_attn_fwd", _p(qkv), s_len, n, d_model, num_heads, float(dropout_p), int(seed), _p(out),
-                  _p(lse), _stream(qkv))
-        ctx.save_for_backward(qkv, out, lse)
+        _lib.call("hivt_temporal_attn_fwd", _p(qkv), s_len, n, d_model, num_heads, float(dropout_p), int(seed),
+                  _seed_ptr(dropout_p), _p(out), _p(lse), _stream(qkv))
+        ctx.save_for_backward(qkv, out, lse, DEVICE_SEED if dropout_p > 0.0 else None)
         ctx.cfg = (int(num_heads), float(dropout_p), int(seed))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out):
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, lse, seed_dev = ctx.saved_tensors
         num_heads, dropout_p, seed = ctx.cfg
         s_len, n, three_d = qkv.shape
         d_out = d_out.contiguous()
         d_qkv = torch.empty_like(qkv)
         _lib.call("hivt_temporal_attn_bwd", _p(d_out), _p(qkv), _p(out), _p(lse), s_len, n, three_d // 3, num_heads,
-                  dropout_p, seed, _p(d_qkv), _stream(qkv))
+                  dropout_p, seed, _p(seed_dev), _p(d_qkv), _stream(qkv))
         return d_qkv, None, None, None
 
 

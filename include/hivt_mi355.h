@@ -81,9 +81,13 @@ size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows);
  * positions in ascending order inside a row.  Replaces the implicit grouping done by
  * torch_geometric's scatter in MessagePassing.propagate(aggr='add') and utils.softmax
  * (call sites models/local_encoder.py:98,179,292,369; models/global_interactor.py:75,122).
- *   key int32 [E] with values in [0,num_rows); rowptr int32 [num_rows+1]; perm int32 [E]. */
-int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, int32_t* rowptr, int32_t* perm,
-                   void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+ *   key int32 [E] with values in [0,num_rows); rowptr int32 [num_rows+1]; perm int32 [E].
+ * `count` (device int32, may be NULL) gives the number of meaningful entries when the list is
+ * padded to a fixed capacity E: entries at or beyond *count are ignored, rowptr[num_rows] = *count
+ * and perm[*count .. E) is left untouched.  This lets a captured HIP graph be replayed on batches
+ * with different edge counts. */
+int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,
+                   int32_t* perm, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel (a): edge gather + rotation into the target's frame
@@ -95,23 +99,25 @@ int hivt_csr_build(const int32_t* key, int64_t E, int32_t num_rows, int32_t* row
  * (models/local_encoder.py:165-166, 352-356).  Also emits src/dst in the output order when
  * src_csr / dst_csr are non-NULL.
  *   x_src float [Ns, x_stride] (2 used), attr float [E,2], rot float [Nr,2,2] row-major,
- *   out float [E,4]. */
+ *   out float [E,4].  With `count` (device int32, may be NULL) rows e >= *count are padding of a
+ *   fixed-capacity list and receive zeros / index 0. */
 int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride, const float* attr, const float* rot,
                                 const int32_t* src, const int32_t* dst, const int32_t* perm, int32_t rot_mod,
-                                int64_t E, float* out, int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream);
+                                int64_t E, const int32_t* count, float* out, int32_t* src_csr, int32_t* dst_csr,
+                                hivt_stream_t stream);
 
 /* Gradient of the above w.r.t. attr (d_attr, original edge order, may be NULL) and x_src
  * (d_x float [Ns,2], must be zero-filled by the caller, accumulated with float atomics, may be
  * NULL).  Needed only when positions / features require grad (never in the reference's step). */
 int hivt_edge_gather_rotate_bwd(const float* d_out, const float* rot, const int32_t* src, const int32_t* dst,
-                                const int32_t* perm, int32_t rot_mod, int64_t E, float* d_attr, float* d_x,
-                                hivt_stream_t stream);
+                                const int32_t* perm, int32_t rot_mod, int64_t E, const int32_t* count,
+                                float* d_attr, float* d_x, hivt_stream_t stream);
 
 /* Relative pose features of GlobalInteractor.forward (models/global_interactor.py:54-58):
  * out[e] = [ attr[p] @ R[dst[p]],  cos(theta[src[p]]-theta[dst[p]]),  sin(...) ], p = perm[e]. */
 int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angles, const int32_t* src,
-                          const int32_t* dst, const int32_t* perm, int64_t E, float* out, int32_t* src_csr,
-                          int32_t* dst_csr, hivt_stream_t stream);
+                          const int32_t* dst, const int32_t* perm, int64_t E, const int32_t* count, float* out,
+                          int32_t* src_csr, int32_t* dst_csr, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernels (b)+(c): per-edge QK dot, segment softmax over CSR rows, weighted sum of V
@@ -124,21 +130,26 @@ int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angl
  * (models/local_encoder.py:174-181, 364-371 and :98, :292; models/global_interactor.py:115-124, :75).
  * k / v rows are in CSR order with element stride kv_stride (so a fused [E,2D] K|V buffer works).
  * Saves the per-(row,head) max `m_out` and denominator `den_out` (float [N,H]) for backward.
- * Dropout (p > 0) uses a counter-based generator keyed on (seed, CSR position, head). */
+ * Dropout (p > 0) uses a counter-based generator keyed on (seed + *seed_ptr, CSR position, head);
+ * seed_ptr (device uint64, may be NULL) lets a captured graph draw fresh masks on every replay.
+ * E is the number of k / v rows (a fixed capacity is fine: rows beyond rowptr[N] are never read). */
 int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                       const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                      int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
-                      float* m_out, float* den_out, int dtype, hivt_stream_t stream);
+                      int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                      const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                      hivt_stream_t stream);
 
 /* Backward of hivt_seg_attn_fwd: dq float [N,D]; dk / dv float rows in CSR order with element
  * stride dkv_stride (gradient of the per-edge key/value, i.e. also of k_node[src[e]] before it is
  * summed per source -- use hivt_segment_sum_rows over a CSR-by-source for that).  The max is
- * treated as a constant, as torch_geometric detaches it. */
+ * treated as a constant, as torch_geometric detaches it.  With zero_tail != 0 the rows
+ * [rowptr[N], E) of dk / dv (padding of a fixed-capacity list) are set to zero. */
 int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
                       const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                       const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                      int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
-                      float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream);
+                      int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
+                      float* dq, float* dk, float* dv, int64_t dkv_stride, int32_t zero_tail, int dtype,
+                      hivt_stream_t stream);
 
 /* hivt_seg_attn_fwd / _bwd with in-application timing: identical computation; additionally the
  * launch records the kernel's own start and stop time stamps into the two hipEvent_t handles
@@ -146,15 +157,15 @@ int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const 
  * dispatch gaps that events recorded around a launch include.  No counterpart in the reference. */
 int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                             const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                            int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* out,
-                            float* m_out, float* den_out, int dtype, hivt_stream_t stream, void* start_event,
-                            void* stop_event);
+                            int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                            const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                            hivt_stream_t stream, void* start_event, void* stop_event);
 int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
                             const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                             const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                            int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* dq, float* dk,
-                            float* dv, int64_t dkv_stride, int dtype, hivt_stream_t stream, void* start_event,
-                            void* stop_event);
+                            int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                            const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
+                            int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event, void* stop_event);
 
 /* out[r, 0:width] = sum_{i in rowptr[r]..rowptr[r+1]} rows[perm[i], 0:width] in ascending i
  * (deterministic scatter-add without atomics; perm == NULL reads rows[i]).  Used for the
@@ -239,12 +250,12 @@ int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, co
  * TemporalEncoderLayer._sa_block (models/local_encoder.py:271-276, mask :237-241) including its
  * dropout on the attention weights.  Saves lse float [N,H,S] for the backward. */
 int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p,
-                           uint64_t seed, float* out, float* lse, hivt_stream_t stream);
+                           uint64_t seed, const uint64_t* seed_ptr, float* out, float* lse, hivt_stream_t stream);
 
 /* Backward of the above: d_qkv float [S,N,3D] from d_out [S,N,D], the forward inputs / outputs. */
 int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse, int32_t S,
-                           int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed, float* d_qkv,
-                           hivt_stream_t stream);
+                           int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
+                           float* d_qkv, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused regression / classification loss (min over modes + Laplace NLL + soft-target CE)
