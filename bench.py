@@ -55,6 +55,19 @@ def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool) 
     return float(b)
 
 
+def measured_traffic(embed_dim: int, scenes: int):
+    """HBM bytes per launch from the committed counter passes (profiles/*_seg_attn_traffic.json, latest
+    file whose workload matches), keyed "kind/caller"; empty when none applies."""
+    import glob
+    best = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_seg_attn_traffic.json"))):
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("workload") == {"embed_dim": embed_dim, "scenes_per_gpu": scenes}:
+            best = {k: v["hbm_bytes"] for k, v in doc["per_launch"].items()}
+    return best
+
+
 def cpu_baseline(embed_dim: int, scenes: int, steps: int):
     """The CPU oracle's G + D + R1 step (forward, both backwards, both AdamW updates) on a bounded
     sample of the same workload; returns scenes/sec on the host cores torch is allowed to use."""
@@ -168,11 +181,12 @@ def main():
         for kind, tag, n, e, d, h, node_terms, ev0, ev1 in records:
             groups.setdefault((kind, tag, node_terms, d, h), []).append((n, e, ev0.elapsed_time(ev1) * 1e-3))
         roofline, extra = None, []
+        traffic = measured_traffic(args.embed_dim, args.scenes)
         for (kind, tag, node_terms, d, h), rows in groups.items():
             by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms) for n, e, _ in rows) / len(rows)
             tm = sum(r[2] for r in rows) / len(rows)
             entry = {"kernel": f"seg_attn_{kind}_kernel", "caller": tag, "bound": "hbm", "achieved": by / tm / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / tm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / tm / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get(f"{kind}/{tag}"),
                      "bytes_per_launch": by, "avg_launch_us": tm * 1e6, "launches": len(rows),
                      "edges_per_launch": sum(r[1] for r in rows) / len(rows),
                      "rows_per_launch": sum(r[0] for r in rows) / len(rows)}
