@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-guards", action="store_true",
+                    help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
     ap.add_argument("--cpu-scenes", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
@@ -138,13 +140,16 @@ def main():
     torch.manual_seed(2022)
     model = hv.HiVT(**model_config(args.embed_dim)).to(dev)
     model.train()
-    trainer = hv.GanTrainer(model)
 
     # synthetic batches, resident in HBM before the timed region; distinct scenes per rank
     pool = []
     for i in range(args.pool):
         b = hv.make_batch(args.scenes, first_index=(rank * args.pool + i) * args.scenes).to(dev)
         pool.append((b, b["y"]))
+    # capacities of the filtered edge lists, measured once over the pool with 10 % head room: with them
+    # the step needs no host read-back (live counts, guards and the overflow flag stay on the device)
+    capacity = None if args.host_guards else hv.GanTrainer.calibrate(model, [b for b, _ in pool]).edge_capacity
+    trainer = hv.GanTrainer(model, edge_capacity=capacity)
     torch.manual_seed(1000 + rank)  # dropout streams differ per rank
 
     def run_step(i: int):
@@ -201,7 +206,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"HiVT-{args.embed_dim} full G+D+R1 train step, {args.scenes} synthetic "
                                    f"nuScenes-shaped scenes per GPU per step, dropout 0.1, AdamW x2",
-                       "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}"},
+                       "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
+                       "guards": "host" if args.host_guards else "device",
+                       "discarded_steps": trainer.overflowed_steps()},
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
         }

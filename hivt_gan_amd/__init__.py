@@ -9,7 +9,7 @@ Public surface (same names, constructor arguments and forward signatures as the 
 The sparse arithmetic runs in hand-written gfx950 kernels reached through ``libhivt_mi355.so``.
 """
 from .critics import BaseTrajectoryCritic, LongScaleCritic, MidScaleCritic, ShortScaleCritic
-from .data import TemporalData, collate, make_batch, make_scene
+from .data import BatchSpec, TemporalData, collate, make_batch, make_scene, pad_batch
 from .decoder import MLPDecoder
 from .embedding import MultipleInputEmbedding, SingleInputEmbedding, init_weights
 from .global_interactor import GlobalInteractor, GlobalInteractorLayer
@@ -26,5 +26,5 @@ __all__ = [
     "ShortScaleCritic", "MidScaleCritic", "LongScaleCritic", "LaplaceNLLLoss", "SoftTargetCrossEntropyLoss",
     "R1Regularization", "AdversarialDiscriminatorLoss", "AdversarialGeneratorLoss", "fused_supervised_losses", "HiVT",
     "TemporalData", "collate", "make_scene", "make_batch", "DistanceDropEdge", "EdgePlan", "build_edge_plan",
-    "subgraph", "init_weights", "GanTrainer",
+    "subgraph", "init_weights", "GanTrainer", "BatchSpec", "pad_batch",
 ]

@@ -44,6 +44,18 @@ void set_error(const char* fmt, ...);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Zero `words` 32-bit words with a kernel.  The library never uses the runtime's memset: a memset
+// recorded into a HIP graph is a separate node type, and every launch here must stay a plain
+// kernel node so that a recorded step replays safely.
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int64_t words);
+inline void zero_words(void* p, int64_t words, hipStream_t stream) {
+  if (words <= 0) return;
+  int64_t blocks = (words + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(p),
+                     words);
+}
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

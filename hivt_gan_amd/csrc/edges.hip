@@ -167,7 +167,8 @@ template <class Pred>
 int run_filter(const Pred& pred, int64_t items, int32_t* src_out, int32_t* dst_out, float* attr_out,
                int32_t* count_out, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
   if (items == 0) {
-    HIVT_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int32_t), stream), what);
+    zero_words(count_out, 1, stream);
+    HIVT_CHECK_LAUNCH(what);
     return HIVT_OK;
   }
   const int64_t tiles = (items + kFilterTile - 1) / kFilterTile;
@@ -328,7 +329,8 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* coun
   int32_t* tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) +
                                             align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256));
   // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
-  HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), stream), what);
+  zero_words(cursor, num_rows > 0 ? num_rows : 1, stream);
+  HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
     hipLaunchKernelGGL(csr_hist_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, count,
                        cursor);
@@ -338,7 +340,8 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* coun
                      rowptr + num_rows);
   HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
-    HIVT_CHECK_HIP(hipMemsetAsync(cursor, 0, (size_t)num_rows * sizeof(int32_t), stream), what);
+    zero_words(cursor, num_rows, stream);
+    HIVT_CHECK_LAUNCH(what);
     hipLaunchKernelGGL(csr_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, count,
                        rowptr, cursor, tmp);
     HIVT_CHECK_LAUNCH(what);

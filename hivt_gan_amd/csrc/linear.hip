@@ -574,8 +574,9 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   HIVT_REQUIRE(dw != nullptr, HIVT_ERR_ARG, "%s: dw is null", what);
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) {
-    HIVT_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), s), what);
-    if (dbias) HIVT_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), s), what);
+    zero_words(dw, (int64_t)N * K, s);
+    if (dbias) zero_words(dbias, N, s);
+    HIVT_CHECK_LAUNCH(what);
     return HIVT_OK;
   }
   HIVT_REQUIRE(dy && x, HIVT_ERR_ARG, "%s: null pointer", what);
@@ -625,8 +626,9 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
   HIVT_REQUIRE(dgamma && dbeta, HIVT_ERR_ARG, "%s: null gradient output", what);
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) {
-    HIVT_CHECK_HIP(hipMemsetAsync(dgamma, 0, (size_t)N * sizeof(float), s), what);
-    HIVT_CHECK_HIP(hipMemsetAsync(dbeta, 0, (size_t)N * sizeof(float), s), what);
+    zero_words(dgamma, N, s);
+    zero_words(dbeta, N, s);
+    HIVT_CHECK_LAUNCH(what);
     return HIVT_OK;
   }
   HIVT_REQUIRE(dy && z && stats && gamma && beta && dz, HIVT_ERR_ARG, "%s: null pointer", what);

@@ -279,3 +279,100 @@ def make_scene(index: int,
 def make_batch(num_scenes: int, first_index: int = 0, **scene_kwargs) -> TemporalData:
     """``num_scenes`` consecutive synthetic scenes collated into one batch (CPU tensors)."""
     return collate([make_scene(first_index + i, **scene_kwargs) for i in range(num_scenes)])
+
+
+# --------------------------------------------------------------------------------------
+# Fixed-shape batches
+# --------------------------------------------------------------------------------------
+class BatchSpec:
+    """Tensor capacities of a fixed-shape batch.
+
+    A training step whose tensor shapes never change needs no shape-dependent host work (allocation
+    sizes, launch grids, read-backs of counts).  ``pad_batch`` brings every batch to these
+    capacities; the padding is inert by construction:
+
+    * padded agents are masked at every step (``padding_mask`` true), so the validity filter drops
+      every edge that touches them and every loss weights them with zero;
+    * padded agent-agent pairs are self loops of the last (always padded) agent;
+    * padded lane-actor pairs carry a vector far outside any radius, so the radius filter drops them.
+
+    ``edge_capacity`` bounds the three FILTERED edge lists (agent-agent over all history steps,
+    lane-actor, last-step interaction); the kernels read the live counts from device memory.
+    """
+
+    def __init__(self, num_nodes: int, num_lanes: int, num_edges: int, num_lane_actor: int,
+                 edge_capacity: Optional[tuple] = None) -> None:
+        self.num_nodes = int(num_nodes)
+        self.num_lanes = int(num_lanes)
+        self.num_edges = int(num_edges)
+        self.num_lane_actor = int(num_lane_actor)
+        self.edge_capacity = tuple(int(c) for c in edge_capacity) if edge_capacity is not None else None
+
+    @staticmethod
+    def covering(batches: Iterable[TemporalData], slack: float = 1.05, multiple: int = 64) -> "BatchSpec":
+        """Smallest spec (rounded up) that holds every batch of ``batches`` with ``slack`` head room."""
+        def up(v: float) -> int:
+            return int(-(-int(v * slack + 1) // multiple) * multiple)
+        n = l = e = la = 0
+        for b in batches:
+            n = max(n, int(b.num_nodes))
+            l = max(l, int(b["lane_vectors"].shape[0]))
+            e = max(e, int(b["edge_index"].shape[1]))
+            la = max(la, int(b["lane_actor_index"].shape[1]))
+        return BatchSpec(up(n + 1), up(l), up(e), up(la))
+
+    def __repr__(self) -> str:
+        return (f"BatchSpec(num_nodes={self.num_nodes}, num_lanes={self.num_lanes}, num_edges={self.num_edges}, "
+                f"num_lane_actor={self.num_lane_actor}, edge_capacity={self.edge_capacity})")
+
+
+_FAR = 1.0e6  # metres; outside every radius
+
+
+def _pad_rows(t: torch.Tensor, rows: int, value) -> torch.Tensor:
+    out = torch.full((rows,) + tuple(t.shape[1:]), value, dtype=t.dtype, device=t.device)
+    out[:t.shape[0]] = t
+    return out
+
+
+def pad_batch(batch: TemporalData, spec: BatchSpec, out: Optional[TemporalData] = None) -> TemporalData:
+    """``batch`` brought to the capacities of ``spec`` (see ``BatchSpec`` for why the padding is inert).
+    With ``out`` (a batch previously produced for the same spec) the tensors are written in place, so
+    their addresses stay fixed."""
+    n = int(batch.num_nodes)
+    if n + 1 > spec.num_nodes:
+        raise ValueError(f"batch has {n} agents; the spec needs at least one spare row beyond them "
+                         f"(capacity {spec.num_nodes})")
+    e, la, nl = batch["edge_index"].shape[1], batch["lane_actor_index"].shape[1], batch["lane_vectors"].shape[0]
+    if e > spec.num_edges or la > spec.num_lane_actor or nl > spec.num_lanes:
+        raise ValueError(f"batch exceeds {spec}: {e} pairs, {la} lane-actor pairs, {nl} lanes")
+    last = spec.num_nodes - 1
+    fields: Dict[str, object] = {}
+    node_pad = {"x": 0.0, "positions": 0.0, "y": 0.0, "padding_mask": True, "bos_mask": False, "rotate_angles": 0.0}
+    for k, v in node_pad.items():
+        fields[k] = _pad_rows(batch[k], spec.num_nodes, v)
+    for k in ("lane_vectors", "is_intersections", "turn_directions", "traffic_controls"):
+        fields[k] = _pad_rows(batch[k], spec.num_lanes, 0)
+    ei = torch.full((2, spec.num_edges), last, dtype=torch.long, device=batch["edge_index"].device)
+    ei[:, :e] = batch["edge_index"]
+    fields["edge_index"] = ei
+    lai = torch.zeros((2, spec.num_lane_actor), dtype=torch.long, device=ei.device)
+    lai[1] = last
+    lai[:, :la] = batch["lane_actor_index"]
+    fields["lane_actor_index"] = lai
+    fields["lane_actor_vectors"] = _pad_rows(batch["lane_actor_vectors"], spec.num_lane_actor, _FAR)
+    if out is None:
+        out = TemporalData(**fields)
+        out["num_nodes"] = spec.num_nodes
+        out["_num_graphs"] = batch.num_graphs
+        out["edge_capacity"] = spec.edge_capacity
+        for k in ("agent_index", "av_index"):
+            if k in batch:
+                out[k] = batch[k]
+        return out
+    for k, v in fields.items():
+        out[k].copy_(v)
+    for k in ("agent_index", "av_index"):
+        if k in batch:
+            out[k] = batch[k]
+    return out

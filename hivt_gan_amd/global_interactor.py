@@ -61,7 +61,8 @@ class GlobalInteractorLayer(nn.Module):
         kv_edge = _fused_linear(edge_attr, self.lin_k_edge, self.lin_v_edge)
         agg = ops.seg_attn(q, kv_edge, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
-                           perm_by_src=edges.perm_by_src, tag=type(self).__name__)
+                           perm_by_src=edges.perm_by_src, tag=type(self).__name__,
+                           padded=edges.count is not None)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(x, self.lin_hh, self.lin_self))
         return self.proj_drop(_linear(upd, self.out_proj))
 
@@ -98,11 +99,11 @@ class GlobalInteractor(nn.Module):
         if data["rotate_mat"] is None:
             # un-rotated relative positions in CSR order (global_interactor.py:51-52)
             feat, src_csr, _ = ops.edge_gather_rotate(edges.coo_attr.new_zeros(edges.num_src, 2), edges.coo_attr, None,
-                                                      edges.coo_src, edges.coo_dst, edges.perm, 1)
+                                                      edges.coo_src, edges.coo_dst, edges.perm, 1, edges.count)
             rel_embed = self.rel_embed(feat[:, 2:4])
         else:
             feat, src_csr, _ = ops.edge_relpose(edges.coo_attr, data["rotate_mat"], data["rotate_angles"],
-                                                edges.coo_src, edges.coo_dst, edges.perm)
+                                                edges.coo_src, edges.coo_dst, edges.perm, edges.count)
             rel_embed = self.rel_embed.forward_packed(feat)
         edges.src = src_csr
         x = local_embed

@@ -50,6 +50,9 @@ class HiVT(nn.Module):
         self.short_horizon, self.mid_horizon = short_horizon, mid_horizon
         self.critic_lr = critic_lr
         self.check_finite = bool(kwargs.get("check_finite", True))
+        # sync_free: the guards of the training step stay on the device (no host read-back, no
+        # data-dependent control flow), so the host can keep launching ahead of the GPU
+        self.sync_free = bool(kwargs.get("sync_free", False))
 
         self.local_encoder = LocalEncoder(historical_steps=historical_steps, node_dim=node_dim, edge_dim=edge_dim,
                                           embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,
@@ -127,13 +130,22 @@ class HiVT(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def training_step(self, data, opt_g: torch.optim.Optimizer, opt_d: Optional[torch.optim.Optimizer] = None,
-                      sync_grads: Optional[Callable[[str], None]] = None) -> Dict[str, torch.Tensor]:
-        """One optimisation step; returns detached loss tensors (no host read-back here).
+                      sync_grads: Optional[Callable[..., None]] = None) -> Dict[str, torch.Tensor]:
+        """One optimisation step; returns detached loss tensors (no host read-back of losses).
 
-        ``sync_grads(group)`` is called after each backward with ``"critic"`` or ``"generator"`` and must
-        average that group's gradients across data-parallel ranks.  A rank whose batch trips a guard
-        still calls it (with zero gradients) so every rank enters the same collectives
-        (``models/hivt.py:262-265,301-310``)."""
+        ``sync_grads(group, bad)`` is called after each backward with ``"critic"`` or ``"generator"`` and
+        must average that group's gradients across data-parallel ranks; ``bad`` is ``None`` or a device
+        bool telling that this rank's gradients must enter the average as zeros.  A rank whose batch
+        trips a guard still calls it so every rank enters the same collectives
+        (``models/hivt.py:262-265,301-310``).
+
+        Guards: a NaN target or a non-finite prediction discards the batch.  By default they are
+        evaluated on the host (two read-backs per step).  With ``sync_free`` they stay on the device:
+        without data parallelism the optimizers skip their update through ``found_inf`` (fused AdamW),
+        with it the rank contributes zero gradients -- the same outcomes without any synchronisation."""
+        if self.sync_free:
+            return self._training_step_sync_free(data, opt_g, opt_d, sync_grads)
+
         def skip(reason: str) -> Dict[str, torch.Tensor]:
             # zero-gradient participation keeps data-parallel ranks in lock-step
             for group, opt in (("critic", opt_d), ("generator", opt_g)):
@@ -143,7 +155,7 @@ class HiVT(nn.Module):
                     # the other ranks step with the averaged gradient; so must this one, or the
                     # replicas drift apart.  Without data parallelism a skipped batch changes nothing.
                     opt.zero_grad(set_to_none=False)
-                    sync_grads(group)
+                    sync_grads(group, None)
                     opt.step()
             return {"skipped": torch.ones((), device=data["y"].device)}
 
@@ -152,6 +164,31 @@ class HiVT(nn.Module):
         y_hat, pi = self(data)
         if self.check_finite and not bool(torch.isfinite(y_hat).all()):  # models/hivt.py:272,294
             return skip("non-finite prediction")
+        return self._losses_and_updates(data, y_hat, pi, opt_g, opt_d, sync_grads, None)
+
+    def _training_step_sync_free(self, data, opt_g, opt_d, sync_grads) -> Dict[str, torch.Tensor]:
+        y_raw = data["y"]
+        y_hat, pi = self(data)
+        bad = torch.zeros((), dtype=torch.bool, device=y_hat.device)
+        if self.check_finite:
+            bad = torch.isnan(y_raw).any() | ~torch.isfinite(y_hat).all()
+        plan = data.get("edge_plan")
+        if plan is not None and plan.overflow is not None:
+            bad = bad | plan.overflow  # a fixed-capacity edge list was truncated: discard the batch
+        logs = self._losses_and_updates(data, y_hat, pi, opt_g, opt_d, sync_grads, bad)
+        logs["skipped"] = bad.float()
+        return logs
+
+    def _losses_and_updates(self, data, y_hat, pi, opt_g, opt_d, sync_grads, bad) -> Dict[str, torch.Tensor]:
+        found_inf = bad.float() if bad is not None else None
+
+        def update(group: str, opt: torch.optim.Optimizer) -> None:
+            if sync_grads is not None:
+                sync_grads(group, bad)
+            elif found_inf is not None:
+                opt.found_inf = found_inf  # read by the fused AdamW kernels: 1 leaves parameters and state untouched
+            opt.step()
+
         reg_loss, cls_loss, best_mode = self._supervised_losses(data, y_hat, pi)
         logs: Dict[str, torch.Tensor] = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
 
@@ -159,9 +196,7 @@ class HiVT(nn.Module):
             loss = reg_loss + cls_loss
             opt_g.zero_grad(set_to_none=True)
             loss.backward()
-            if sync_grads is not None:
-                sync_grads("generator")
-            opt_g.step()
+            update("generator", opt_g)
             logs["loss"] = loss.detach()
             return logs
 
@@ -171,9 +206,7 @@ class HiVT(nn.Module):
             d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
             opt_d.zero_grad(set_to_none=True)
             d_loss.backward()
-            if sync_grads is not None:
-                sync_grads("critic")
-            opt_d.step()
+            update("critic", opt_d)
         # generator update (models/hivt.py:317-327); critic weight gradients of this backward would be
         # discarded by the next opt_d.zero_grad(), so they are not computed at all
         for p in critic_params:
@@ -186,9 +219,7 @@ class HiVT(nn.Module):
         finally:
             for p in critic_params:
                 p.requires_grad_(True)
-        if sync_grads is not None:
-            sync_grads("generator")
-        opt_g.step()
+        update("generator", opt_g)
         logs.update({"d_loss": d_loss.detach(), "g_adv": g_adv.detach(), "g_total": g_total.detach()})
         logs.update(d_logs)
         logs.update(g_logs)

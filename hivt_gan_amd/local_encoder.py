@@ -35,6 +35,8 @@ class EdgePlan:
     agent_agent: EdgeSet   # all timesteps, node id t*N + n        (local_encoder.py:58-61,65)
     lane_actor: EdgeSet    # lane -> actor within the radius        (local_encoder.py:80)
     interaction: EdgeSet   # agents valid at the last history step  (global_interactor.py:48-50)
+    overflow: Optional[torch.Tensor] = None  # device bool: a filtered list exceeded its fixed capacity
+    counts: Optional[torch.Tensor] = None    # device int32 [3]: unclamped live counts (fixed-capacity mode)
 
 
 class DistanceDropEdge:
@@ -63,20 +65,33 @@ def subgraph(subset: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tens
 
 
 def build_edge_plan(data, historical_steps: int, local_radius: Optional[float]) -> EdgePlan:
-    """All three edge sets of a batch, filtered and CSR-grouped on the device."""
+    """All three edge sets of a batch, filtered and CSR-grouped on the device.
+
+    Without ``data["edge_capacity"]`` the three live counts are read back once and the lists are cut
+    to size.  With it (three integers, see ``BatchSpec``) nothing is read back: the lists keep their
+    fixed capacity, every consumer takes the live count from device memory, and ``overflow`` records on
+    the device whether a filtered list did not fit (the step must then be discarded)."""
     T = historical_steps
     n = int(data.num_nodes)
     num_lanes = int(data["lane_vectors"].shape[0])
     aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
     la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
     gi = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], T - 1, 1, None)
-    counts = torch.cat([aa[3], la[3], gi[3]]).cpu()  # the only host synchronisation of the forward pass
-    e_aa, e_la, e_gi = (int(c) for c in counts)
-    plan = EdgePlan(
-        agent_agent=ops.make_edge_set(aa[0][:e_aa], aa[1][:e_aa], aa[2][:e_aa], T * n, T * n),
-        lane_actor=ops.make_edge_set(la[0][:e_la], la[1][:e_la], la[2][:e_la], num_lanes, n),
-        interaction=ops.make_edge_set(gi[0][:e_gi], gi[1][:e_gi], gi[2][:e_gi], n, n))
-    return plan
+    shapes = ((T * n, T * n), (num_lanes, n), (n, n))
+    caps = data.get("edge_capacity")
+    if caps is None:
+        counts = torch.cat([aa[3], la[3], gi[3]]).cpu()  # the only host synchronisation of the forward pass
+        sets = [ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd)
+                for lst, c, (ns, nd) in zip((aa, la, gi), (int(c) for c in counts), shapes)]
+        return EdgePlan(*sets)
+    caps = [min(int(c), int(lst[0].shape[0])) for c, lst in zip(caps, (aa, la, gi))]
+    sets, overflow = [], None
+    for lst, c, (ns, nd) in zip((aa, la, gi), caps, shapes):
+        sets.append(ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd, count=lst[3].clamp(max=c)))
+        over = lst[3] > c
+        overflow = over if overflow is None else overflow | over
+    counts = torch.cat([aa[3], la[3], gi[3]])
+    return EdgePlan(*sets, overflow=overflow.view(()), counts=counts)
 
 
 def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
@@ -127,7 +142,7 @@ class _EdgeAttentionBase(nn.Module):
         kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
         q = _linear(center, self.lin_q)
         agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
-                           tag=type(self).__name__)
+                           tag=type(self).__name__, padded=edges.count is not None)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(center, self.lin_hh, self.lin_self))
         return self.proj_drop(_linear(upd, self.out_proj))
 
@@ -180,7 +195,7 @@ class AAEncoder(_EdgeAttentionBase):
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
                    rot_mod: int) -> torch.Tensor:
         feat, _src, _dst = ops.edge_gather_rotate(x, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
-                                                  edges.perm, rot_mod)
+                                                  edges.perm, rot_mod, edges.count)
         return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges)
 
 
@@ -214,7 +229,7 @@ class ALEncoder(_EdgeAttentionBase):
     def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
                    rotate_mat: Optional[torch.Tensor]) -> torch.Tensor:
         feat, src_csr, _dst = ops.edge_gather_rotate(x_lane, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
-                                                     edges.perm, x_actor.shape[0])
+                                                     edges.perm, x_actor.shape[0], edges.count)
         table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
                  + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
         # rows of the 12-entry table picked per edge as a one-hot GEMM: its backward is a dense

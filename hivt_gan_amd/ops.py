@@ -257,10 +257,10 @@ def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
     rec.append((kind, tag, n, e, d_model, heads, node_terms, ev0, ev1))
 
 
-# Dropout seeds.  Eagerly every call draws a host-side seed (CPU generator: no device sync,
-# reproducible under torch.manual_seed).  When DEVICE_SEED is set (a uint64-as-int64 device scalar
-# owned by the caller) the kernels add its current value to a per-call constant instead, so a
-# captured graph draws new masks on every replay as long as the caller advances the scalar.
+# Dropout seeds.  Every call draws a host-side seed (CPU generator: no device sync, reproducible
+# under torch.manual_seed).  When DEVICE_SEED is set (a uint64-as-int64 device scalar owned by the
+# caller) the kernels add its current value to a per-call constant instead, so a caller that
+# re-issues identical launches still draws new masks as long as it advances the scalar.
 DEVICE_SEED: Optional[torch.Tensor] = None
 _seed_calls = 0
 

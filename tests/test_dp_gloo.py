@@ -71,8 +71,8 @@ def worker(rank, world, port, poison_rank, out_dir):
         reduced = {}
         plain_sync = trainer._sync
 
-        def recording_sync(group):
-            plain_sync(group)
+        def recording_sync(group, bad=None):
+            plain_sync(group, bad)
             reduced[group] = trainer.buckets[group].flat.clone()
         trainer._sync = recording_sync
         batch = hv.make_batch(2, first_index=10 * rank)
@@ -111,7 +111,7 @@ def single_process_reference(poison_rank):
     for r, b in enumerate(batches):
         model.load_state_dict(sn_state, strict=False)  # every rank starts from the same power-iteration state
 
-        def grab(group, r=r):
+        def grab(group, bad=None, r=r):
             ps = cr if group == "critic" else gen
             captured[group].append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in ps])
         if r == poison_rank:

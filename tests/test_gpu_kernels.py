@@ -111,6 +111,23 @@ def test_csr_is_stable_sort(e, rows):
     assert torch.equal(rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
 
 
+def test_csr_of_live_prefix_ignores_the_tail():
+    # fixed-capacity lists: only the first `count` keys are grouped; the tail may hold anything
+    gen = torch.Generator().manual_seed(11)
+    e, rows, live = 20_000, 300, 13_337
+    key = torch.randint(0, rows, (e,), generator=gen, dtype=torch.int32)
+    key[live:] = 7  # in range on purpose: a kernel that looked at the tail would show up in the counts
+    count = torch.tensor([live], dtype=torch.int32, device=DEV)
+    rowptr, perm = ops.csr_build(key.to(DEV), rows, count)
+    order = torch.sort(key[:live].long(), stable=True).indices
+    assert torch.equal(perm[:live].cpu().long(), order)
+    counts = torch.bincount(key[:live].long(), minlength=rows)
+    assert torch.equal(rowptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+    # a count beyond the capacity is clamped to it
+    rowptr2, _ = ops.csr_build(key[:live].to(DEV), rows, torch.tensor([10 * e], dtype=torch.int32, device=DEV))
+    assert torch.equal(rowptr2, rowptr)
+
+
 def test_csr_repeatable():
     key = torch.randint(0, 300, (100_000,), dtype=torch.int32, device=DEV)
     p0 = ops.csr_build(key, 300)[1]
@@ -282,6 +299,58 @@ def test_seg_attn_dropout_statistics_and_backward_mask():
     # eval mode ignores dropout
     out_eval = ops.seg_attn(q, kv.detach(), rowptr.to(DEV), H, dropout_p=p, training=False)
     assert torch.allclose(out_eval, torch.ones_like(out_eval), atol=2e-6)
+
+
+def test_dropout_seed_from_device_memory():
+    # a device-resident seed is added to the per-call constant: same masks as the summed host seed,
+    # forward and backward, and different masks once the device value moves
+    gen = torch.Generator().manual_seed(4)
+    n, e, D, H, p = 50, 4000, 64, 8, 0.25
+    dst = torch.sort(torch.randint(0, n, (e,), generator=gen)).values
+    rowptr = torch.zeros(n + 1, dtype=torch.int32)
+    rowptr[1:] = torch.bincount(dst, minlength=n).cumsum(0).int()
+    rowptr = rowptr.to(DEV)
+    q = torch.randn(n, D, generator=gen).to(DEV).requires_grad_(True)
+    kv = torch.randn(e, 2 * D, generator=gen).to(DEV).requires_grad_(True)
+    go = torch.randn(n, D, generator=gen).to(DEV)
+
+    def run(device_seed):
+        ops.DEVICE_SEED, ops._seed_calls = device_seed, 0
+        try:
+            out = ops.seg_attn(q, kv, rowptr, H, dropout_p=p, training=True)
+            return (out,) + torch.autograd.grad(out, (q, kv), go)
+        finally:
+            ops.DEVICE_SEED = None
+
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    a = run(seed)
+    const = 0x9E3779B97F4A7C15 & ((1 << 62) - 1)  # constant of the first call after the counter reset
+    out = ops._SegAttn.apply(q, kv, None, rowptr, None, None, None, H, p, const + 123456789, "", False)
+    b = (out,) + torch.autograd.grad(out, (q, kv), go)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    seed.add_(1)
+    c = run(seed)
+    assert not torch.equal(a[0], c[0])
+
+    # temporal attention takes the same device seed
+    S, N = 21, 40
+    qkv = torch.randn(S, N, 3 * D, generator=gen).to(DEV).requires_grad_(True)
+    g2 = torch.randn(S, N, D, generator=gen).to(DEV)
+
+    def run_t(device_seed):
+        ops.DEVICE_SEED, ops._seed_calls = device_seed, 0
+        try:
+            o = ops.temporal_attention(qkv, H, p, True)
+            return (o,) + torch.autograd.grad(o, (qkv,), g2)
+        finally:
+            ops.DEVICE_SEED = None
+
+    t1 = run_t(seed)
+    o = ops._TemporalAttn.apply(qkv, H, p, const + int(seed.item()))
+    t2 = (o,) + torch.autograd.grad(o, (qkv,), g2)
+    for x, y in zip(t1, t2):
+        assert torch.equal(x, y)
 
 
 def test_bad_arguments_raise():

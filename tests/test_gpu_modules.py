@@ -274,7 +274,7 @@ def test_gan_step_gradients_vs_oracle():
     g = b.to(DEV)
     grabbed = {}
 
-    def grab(group):
+    def grab(group, bad=None):
         params = model.critic_parameters() if group == "critic" else model.generator_parameters()
         names = {id(p): k for k, p in model.named_parameters()}
         grabbed[group] = {names[id(p)]: p.grad.detach().clone() for p in params if p.grad is not None}

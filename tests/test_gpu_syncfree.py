@@ -1,0 +1,146 @@
+"""Fixed-shape batches and the read-back-free training step.
+
+The padded step must give the results of the plain step (padding is inert); the step with device-side
+guards must give the results of the host-guarded step and leave the model untouched when a guard
+trips or a fixed-capacity edge list overflows."""
+import copy
+
+import pytest
+import torch
+
+import hivt_gan_amd as hv
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def small_model(dropout=0.0, **kw):
+    torch.manual_seed(7)
+    cfg = dict(embed_dim=64, num_heads=8, dropout=dropout, use_gan=True, num_temporal_layers=2, num_global_layers=2,
+               critic_lr=1e-4)
+    cfg.update(kw)
+    m = hv.HiVT(**cfg).to(DEV)
+    m.train()
+    if dropout == 0.0:  # the critics draw their own masks ([rows, hidden], so they depend on the padding)
+        for critic in m.critics.values():
+            for mod in critic.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+    return m
+
+
+class Hold:
+    """Optimizer stand-in that leaves parameters and gradients alone."""
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def step(self):
+        pass
+
+
+def grads_of(model, data):
+    got = {}
+
+    def grab(group, bad=None):
+        params = model.critic_parameters() if group == "critic" else model.generator_parameters()
+        names = {id(p): k for k, p in model.named_parameters()}
+        got.update({names[id(p)]: p.grad.detach().clone() for p in params if p.grad is not None})
+        for p in params:
+            p.grad = None
+
+    logs = model.training_step(data, Hold(), Hold(), sync_grads=grab)
+    return logs, got
+
+
+def rel_err(a, b):
+    scale = max(float(b.abs().max()), 1e-12)
+    return float((a - b).abs().max()) / scale
+
+
+def test_padding_is_inert():
+    model = small_model()
+    batch = hv.make_batch(6, first_index=300).to(DEV)
+    spec = hv.GanTrainer.calibrate(model, [batch])
+    assert spec.num_nodes > batch.num_nodes and spec.edge_capacity is not None
+    padded = hv.pad_batch(batch, spec)
+    sn = {k: v.clone() for k, v in model.state_dict().items() if k.endswith("_u") or k.endswith("_v")}
+    logs_a, grads_a = grads_of(model, batch)
+    model.load_state_dict(sn, strict=False)
+    model.sync_free = True
+    logs_b, grads_b = grads_of(model, padded)
+    assert float(logs_b["skipped"]) == 0.0
+    for k in ("reg_loss", "cls_loss", "d_loss", "g_adv", "g_total"):
+        assert rel_err(logs_b[k], logs_a[k]) < 1e-5, k
+    assert grads_a.keys() == grads_b.keys()
+    gmax = max(float(g.abs().max()) for g in grads_a.values())
+    for k, g in grads_a.items():
+        err = float((grads_b[k] - g).abs().max())
+        assert err <= 2e-5 * max(float(g.abs().max()), 1e-3 * gmax), (k, err)
+    # the padded plan holds exactly the plain plan's edges
+    plan_a, plan_b = batch["edge_plan"], padded["edge_plan"]
+    na, nb = int(batch.num_nodes), int(padded.num_nodes)
+    for which, (ea, eb) in enumerate(((plan_a.agent_agent, plan_b.agent_agent), (plan_a.lane_actor, plan_b.lane_actor),
+                                      (plan_a.interaction, plan_b.interaction))):
+        n = ea.num_edges
+        assert int(eb.count) == n and int(eb.rowptr[-1]) == n
+        src_b, dst_b = eb.coo_src[:n], eb.coo_dst[:n]
+        if which == 0:  # node id t * N + n: re-base the padded ids to the plain node count
+            src_b = (src_b // nb) * na + src_b % nb
+            dst_b = (dst_b // nb) * na + dst_b % nb
+        assert torch.equal(src_b, ea.coo_src) and torch.equal(dst_b, ea.coo_dst)
+        assert torch.equal(eb.coo_attr[:n], ea.coo_attr)
+
+
+def test_read_back_free_trainer_matches_host_guarded_trainer():
+    batches = [hv.make_batch(6, first_index=400 + 6 * i).to(DEV) for i in range(3)]
+    base = small_model()
+    spec = hv.GanTrainer.calibrate(base, batches)
+    plain_model, free_model = copy.deepcopy(base), copy.deepcopy(base)
+    plain = hv.GanTrainer(plain_model)
+    free = hv.GanTrainer(free_model, edge_capacity=spec.edge_capacity)
+    assert free_model.sync_free and not plain_model.sync_free
+    for i in (0, 1, 2, 1):
+        a, b = batches[i].clone(), batches[i].clone()
+        la, lb = plain.step(a), free.step(b)
+        assert float(lb["skipped"]) == 0.0
+        for k in ("reg_loss", "cls_loss", "d_loss", "g_total"):
+            assert rel_err(lb[k], la[k]) < 1e-4, (i, k, float(lb[k]), float(la[k]))
+    assert free.overflowed_steps() == 0
+    pa, pb = dict(plain_model.named_parameters()), dict(free_model.named_parameters())
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 2e-4, k  # four AdamW steps of lr 5e-4 move weights by ~2e-3
+
+
+def test_device_side_guards_skip_the_update():
+    batches = [hv.make_batch(4, first_index=500 + 4 * i).to(DEV) for i in range(2)]
+    model = small_model()
+    spec = hv.GanTrainer.calibrate(model, batches)
+    tr = hv.GanTrainer(model, edge_capacity=spec.edge_capacity)
+    tr.step(batches[0].clone())
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    poisoned = batches[0].clone()
+    poisoned["y"][0, 0, 0] = float("nan")
+    logs = tr.step(poisoned)
+    assert float(logs["skipped"]) == 1.0
+    for k, v in model.named_parameters():
+        assert torch.equal(v, before[k]), k
+    logs = tr.step(batches[1].clone())
+    assert float(logs["skipped"]) == 0.0
+    assert any(not torch.equal(v, before[k]) for k, v in model.named_parameters())
+    assert all(bool(torch.isfinite(v).all()) for v in model.parameters())
+
+
+def test_edge_capacity_overflow_discards_the_batch():
+    batch = hv.make_batch(4, first_index=520).to(DEV)
+    model = small_model()
+    spec = hv.GanTrainer.calibrate(model, [batch])
+    tight = (spec.edge_capacity[0] // 4, spec.edge_capacity[1], spec.edge_capacity[2])
+    tr = hv.GanTrainer(model, edge_capacity=tight)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    for _ in range(2):
+        logs = tr.step(batch.clone())
+        assert float(logs["skipped"]) == 1.0
+    assert tr.overflowed_steps() == 2
+    for k, v in model.named_parameters():
+        assert torch.equal(v, before[k]), k
