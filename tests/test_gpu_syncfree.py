@@ -108,8 +108,14 @@ def test_read_back_free_trainer_matches_host_guarded_trainer():
             assert rel_err(lb[k], la[k]) < 1e-4, (i, k, float(lb[k]), float(la[k]))
     assert free.overflowed_steps() == 0
     pa, pb = dict(plain_model.named_parameters()), dict(free_model.named_parameters())
+    # Biases whose true gradient is zero by softmax shift invariance (key biases, the last mode-score
+    # bias) receive pure rounding noise, which AdamW normalises to steps of +-lr: not comparable.
+    noise_only = ("lin_k.bias", "lin_k_node.bias", "lin_k_edge.bias", "in_proj_bias", "pi.6.bias")
     for k in pa:
-        assert float((pa[k] - pb[k]).abs().max()) < 2e-4, k  # four AdamW steps of lr 5e-4 move weights by ~2e-3
+        if k.endswith(noise_only):
+            continue
+        err = float((pa[k] - pb[k]).detach().abs().max())
+        assert err < 2e-4, (k, err)  # four AdamW steps of lr 5e-4 move weights by ~2e-3
 
 
 def test_device_side_guards_skip_the_update():
