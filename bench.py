@@ -183,8 +183,9 @@ def main():
 
     if rank == 0:
         groups = {}
-        for kind, tag, n, e, d, h, node_terms, ev0, ev1 in records:
-            groups.setdefault((kind, tag, node_terms, d, h), []).append((n, e, ev0.elapsed_time(ev1) * 1e-3))
+        for kind, tag, n, live, d, h, node_terms, ev0, ev1 in records:
+            groups.setdefault((kind, tag, node_terms, d, h), []).append((n, int(live.item()),
+                                                                         ev0.elapsed_time(ev1) * 1e-3))
         roofline, extra = None, []
         traffic = measured_traffic(args.embed_dim, args.scenes)
         for (kind, tag, node_terms, d, h), rows in groups.items():

@@ -238,12 +238,14 @@ def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, sr
 # Kernels (b)+(c): segment softmax attention
 # --------------------------------------------------------------------------------------------
 # When set to a list, every segment-attention launch appends
-# (kind, tag, rows, edges, D, H, has_node_terms, start_event, end_event) -- device events recorded on
-# the launch stream right around the kernel -- so a benchmark can price the kernel inside a real step.
+# (kind, tag, rows, live_edges, D, H, has_node_terms, start_event, end_event) -- events carrying the
+# kernel's own start / stop time stamps, and the live edge count as a one-element device view of
+# rowptr (fixed-capacity lists hold fewer edges than rows of K|V) -- so a benchmark can price the
+# kernel inside a real step.
 SEG_ATTN_TIMING = None
 
 
-def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
+def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args):
     rec = SEG_ATTN_TIMING
     if rec is None:
         _lib.call(name, *args)
@@ -254,7 +256,7 @@ def _timed_call(kind, tag, n, e, d_model, heads, node_terms, dev, name, *args):
     ev0.record(stream)  # creates the underlying events; the timed launch re-records them with the
     ev1.record(stream)  # kernel's own start / stop time stamps
     _lib.call(name + "_timed", *args, ctypes.c_void_p(ev0.cuda_event), ctypes.c_void_p(ev1.cuda_event))
-    rec.append((kind, tag, n, e, d_model, heads, node_terms, ev0, ev1))
+    rec.append((kind, tag, n, live, d_model, heads, node_terms, ev0, ev1))
 
 
 # Dropout seeds.  Every call draws a host-side seed (CPU generator: no device sync, reproducible
@@ -299,7 +301,7 @@ class _SegAttn(torch.autograd.Function):
         m = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         den = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _timed_call("fwd", tag, n, e, d_model, num_heads, kv_node is not None, q.device,
+        _timed_call("fwd", tag, n, rowptr[n:n + 1], d_model, num_heads, kv_node is not None, q.device,
                     "hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
@@ -321,7 +323,7 @@ class _SegAttn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty(e, 2 * d_model, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _timed_call("bwd", tag, n, e, d_model, num_heads, kv_node is not None, q.device,
+        _timed_call("bwd", tag, n, rowptr[n:n + 1], d_model, num_heads, kv_node is not None, q.device,
                     "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
