@@ -4,12 +4,58 @@ State_dict layout and behaviour follow ``models/critics/base_critic.py:13-44`` (
 ``torch.nn.utils.spectral_norm``: one power iteration per training-mode forward; keys
 ``mlp.{0,3,6,9}.{weight_orig,weight_u,weight_v,bias}``, ``out.*``) and the three horizon
 wrappers (``short_scale_critic.py``, ``mid_scale_critic.py``, ``long_scale_critic.py``).
+
+The spectral normalisation itself is restated in ``SpectralLinear`` instead of being installed as a
+hook: on the GPU all layers of a critic are normalised by ONE kernel launch per forward call (the hook
+issues about a dozen tiny launches per layer and call, nine calls per training step); for CPU tensors
+the same arithmetic runs on framework ops.
 """
 from __future__ import annotations
 
+from typing import List
+
 import torch
 import torch.nn as nn
-from torch.nn.utils import spectral_norm
+import torch.nn.functional as F
+
+from . import ops
+
+_EPS = 1e-12  # default of torch.nn.utils.spectral_norm
+
+
+class SpectralLinear(nn.Module):
+    """``spectral_norm(nn.Linear(in_features, out_features))`` with the hook's parameter / buffer names
+    and initialisation (``weight_orig``, ``bias``, ``weight_u``, ``weight_v``)."""
+
+    def __init__(self, in_features: int, out_features: int) -> None:
+        super().__init__()
+        lin = nn.Linear(in_features, out_features)  # same initial weights and RNG use as the reference
+        self.in_features, self.out_features = in_features, out_features
+        self.bias = lin.bias
+        self.weight_orig = nn.Parameter(lin.weight.data)
+        with torch.no_grad():
+            u = F.normalize(lin.weight.new_empty(out_features).normal_(0, 1), dim=0, eps=_EPS)
+            v = F.normalize(lin.weight.new_empty(in_features).normal_(0, 1), dim=0, eps=_EPS)
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+
+    def normalized_weight(self) -> torch.Tensor:
+        """Framework-op form of the hook's ``compute_weight`` (one power iteration in training mode)."""
+        w, u, v = self.weight_orig, self.weight_u, self.weight_v
+        if self.training:
+            with torch.no_grad():
+                v = F.normalize(torch.mv(w.t(), u), dim=0, eps=_EPS, out=v)
+                u = F.normalize(torch.mv(w, v), dim=0, eps=_EPS, out=u)
+                u, v = u.clone(memory_format=torch.contiguous_format), v.clone(memory_format=torch.contiguous_format)
+        sigma = torch.dot(u, torch.mv(w, v))
+        return w / sigma
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda:
+            (w,) = ops.spectral_normalize([self.weight_orig], [self.weight_u], [self.weight_v], self.training, _EPS)
+        else:
+            w = self.normalized_weight()
+        return F.linear(x, w, self.bias)
 
 
 class BaseTrajectoryCritic(nn.Module):
@@ -18,14 +64,32 @@ class BaseTrajectoryCritic(nn.Module):
         super().__init__()
         blocks, width = [], input_dim
         for _ in range(num_layers):
-            blocks += [spectral_norm(nn.Linear(width, hidden_dim)), nn.LeakyReLU(0.2, inplace=True), nn.Dropout(dropout)]
+            blocks += [SpectralLinear(width, hidden_dim), nn.LeakyReLU(0.2, inplace=True), nn.Dropout(dropout)]
             width = hidden_dim
         self.mlp = nn.Sequential(*blocks)
-        self.out = spectral_norm(nn.Linear(hidden_dim, 1))
+        self.out = SpectralLinear(hidden_dim, 1)
+
+    def _spectral_layers(self) -> List[SpectralLinear]:
+        return [m for m in self.mlp if isinstance(m, SpectralLinear)] + [self.out]
 
     def forward(self, traj: torch.Tensor) -> torch.Tensor:
         """traj [B, T, D] -> realism score [B]."""
-        return self.out(self.mlp(traj.reshape(traj.shape[0], -1))).squeeze(-1)
+        h = traj.reshape(traj.shape[0], -1)
+        layers = self._spectral_layers()
+        if h.is_cuda:
+            weights = ops.spectral_normalize([m.weight_orig for m in layers], [m.weight_u for m in layers],
+                                             [m.weight_v for m in layers], self.training, _EPS)
+        else:
+            weights = [m.normalized_weight() for m in layers]
+        it = iter(zip(layers, weights))
+        for mod in self.mlp:
+            if isinstance(mod, SpectralLinear):
+                lin, w = next(it)
+                h = F.linear(h, w, lin.bias)
+            else:
+                h = mod(h)
+        lin, w = next(it)
+        return F.linear(h, w, lin.bias).squeeze(-1)
 
 
 class _HorizonCritic(BaseTrajectoryCritic):

@@ -596,3 +596,75 @@ def temporal_attention(qkv: torch.Tensor, num_heads: int, dropout_p: float = 0.0
 def temporal_attention_supported(seq_len: int, d_model: int, num_heads: int) -> bool:
     return seq_len <= 32 and (d_model, d_model // num_heads) in ((128, 16), (64, 8), (32, 4), (16, 8), (256, 32)) \
         and (num_heads * 32 <= 256 or (num_heads * 32) % 256 == 0)
+
+
+# --------------------------------------------------------------------------------------------
+# Spectral normalisation of a stack of linear layers (the critics)
+# --------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _SpectralNormalize(torch.autograd.Function):
+    """``(w_0 / sigma_0, ..., w_{L-1} / sigma_{L-1})`` for L weight matrices in one launch; in training
+    mode one power iteration updates the ``u`` / ``v`` buffers in place first."""
+
+    @staticmethod
+    def forward(ctx, state, *weights):
+        us, vs, training, eps = state
+        _need_gpu(*weights)
+        layers = len(weights)
+        ws = [w.contiguous() for w in weights]
+        dev = ws[0].device
+        rows = (ctypes.c_int32 * layers)(*[w.shape[0] for w in ws])
+        cols = (ctypes.c_int32 * layers)(*[w.shape[1] for w in ws])
+        wn = [torch.empty_like(w) for w in ws]
+        # one buffer for every layer's copies of u and v
+        sizes = [w.shape[0] for w in ws] + [w.shape[1] for w in ws]
+        used = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        parts = list(torch.split(used, sizes))
+        u_used, v_used = parts[:layers], parts[layers:]
+        sigma = torch.empty(layers, dtype=torch.float32, device=dev)
+        _lib.call("hivt_spectral_norm_fwd", layers, _ptr_array(ws), _ptr_array(us), _ptr_array(vs), rows, cols,
+                  1 if training else 0, float(eps), _ptr_array(wn), _ptr_array(u_used), _ptr_array(v_used), _p(sigma),
+                  _stream(ws[0]))
+        ctx.save_for_backward(used, sigma, *ws)
+        ctx.sizes = sizes
+        return tuple(wn)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *d_wn):
+        used, sigma, *ws = ctx.saved_tensors
+        layers = len(ws)
+        parts = list(torch.split(used, ctx.sizes))
+        u_used, v_used = parts[:layers], parts[layers:]
+        keep = [i for i, g in enumerate(d_wn) if g is not None]
+        grads = [None] * layers
+        if keep:
+            gs = [d_wn[i].contiguous() for i in keep]
+            outs = [torch.empty_like(ws[i]) for i in keep]
+            sig = sigma if len(keep) == layers else sigma[keep]
+            rows = (ctypes.c_int32 * len(keep))(*[ws[i].shape[0] for i in keep])
+            cols = (ctypes.c_int32 * len(keep))(*[ws[i].shape[1] for i in keep])
+            _lib.call("hivt_spectral_norm_bwd", len(keep), _ptr_array(gs), _ptr_array([ws[i] for i in keep]),
+                      _ptr_array([u_used[i] for i in keep]), _ptr_array([v_used[i] for i in keep]), _p(sig), rows, cols,
+                      _ptr_array(outs), _stream(gs[0]))
+            for i, o in zip(keep, outs):
+                grads[i] = o
+        return (None, *grads)
+
+
+def spectral_normalize(weights, us, vs, training: bool, eps: float = 1e-12):
+    """Spectrally normalised copies of ``weights`` (a list of [out, in] matrices, at most 8).  ``us`` /
+    ``vs`` are the persistent power-iteration vectors; in training mode they advance by one iteration
+    (in place), exactly as the hook of ``torch.nn.utils.spectral_norm`` does per forward call."""
+    if len(weights) > 8:
+        raise ValueError("at most 8 layers per call")
+    for w, u, v in zip(weights, us, vs):
+        if w.dim() != 2 or u.shape != (w.shape[0],) or v.shape != (w.shape[1],):
+            raise ValueError("weights must be [out, in] with u [out] and v [in]")
+        if w.dtype != torch.float32 or not u.is_contiguous() or not v.is_contiguous():
+            raise TypeError("spectral_normalize needs float32 weights and contiguous u / v")
+    _need_gpu(*us, *vs)
+    return _SpectralNormalize.apply((list(us), list(vs), bool(training), eps), *weights)

@@ -288,6 +288,32 @@ int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const
                              int32_t N, int32_t Hf, const int64_t* best, const float* soft, const float* stats,
                              float* d_y_hat, float* d_pi, hivt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Spectral normalisation of the critics' linear layers
+ * ------------------------------------------------------------------------------------------ */
+
+#define HIVT_SPECTRAL_MAX_LAYERS 8 /* layers per call */
+
+/* One power iteration and the division by the singular-value estimate for `layers` weight matrices
+ * in ONE launch (one workgroup per layer).  Replaces, per layer and per forward call, the hook that
+ * torch.nn.utils.spectral_norm installs on the critics' linears (models/critics/base_critic.py:26-38):
+ *     v = normalize(W^T u); u = normalize(W v)      (only if power_iteration != 0; u, v updated in place)
+ *     sigma = u . (W v);  wn = W / sigma
+ * normalize(x) = x / max(||x||_2, eps).  w[l] is float [rows[l], cols[l]] row-major, u[l] [rows[l]],
+ * v[l] [cols[l]].  u_used / v_used receive the vectors sigma was formed with; they are the constants of
+ * the gradient (the hook clones u and v for the same purpose).  The pointer arrays and rows / cols are
+ * HOST arrays of `layers` entries; each side of a matrix is at most 1024. */
+int hivt_spectral_norm_fwd(int32_t layers, const float* const* w, float* const* u, float* const* v,
+                           const int32_t* rows, const int32_t* cols, int32_t power_iteration, float eps,
+                           float* const* wn, float* const* u_used, float* const* v_used, float* sigma,
+                           hivt_stream_t stream);
+
+/* Gradient of the above with u_used, v_used constant:
+ *     d_w = d_wn / sigma - (<d_wn, w> / sigma^2) * u_used v_used^T. */
+int hivt_spectral_norm_bwd(int32_t layers, const float* const* d_wn, const float* const* w,
+                           const float* const* u_used, const float* const* v_used, const float* sigma,
+                           const int32_t* rows, const int32_t* cols, float* const* d_w, hivt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

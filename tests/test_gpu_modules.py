@@ -3,6 +3,7 @@ oracle fed with the same state_dict and the same synthetic batch (dropout 0)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import hivt_gan_amd as hv
 from oracle import hivt_oracle as O
@@ -317,3 +318,59 @@ def test_r1_double_backward_coexists_with_custom_functions():
     assert all(torch.isfinite(v).all() for v in logs.values())
     after = [p.detach() for p in model.critic_parameters()[:2]] + [model.generator_parameters()[0].detach()]
     assert all(not torch.equal(a, c) for a, c in zip(before, after))
+
+
+# ---------------------------------------------------------------------------------------------
+# Critics: fused spectral normalisation
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("training", [True, False])
+def test_critic_spectral_norm_kernel_matches_framework_hook(training):
+    """One launch per critic call against torch.nn.utils.spectral_norm layers holding the same state:
+    scores, the advanced u / v buffers, and the gradients (including R1's double backward)."""
+    import copy
+    from torch.nn.utils import spectral_norm
+
+    torch.manual_seed(5)
+    critic = hv.LongScaleCritic(horizon=30, input_dim=2, hidden_dim=256).to(DEV)
+    for mod in critic.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    # the same network built from hooked framework layers
+    ref_layers = []
+    for m in critic._spectral_layers():
+        lin = spectral_norm(torch.nn.Linear(m.in_features, m.out_features)).to(DEV)
+        lin.load_state_dict(copy.deepcopy(m.state_dict()))
+        ref_layers.append(lin)
+    critic.train(training)
+    for lin in ref_layers:
+        lin.train(training)
+
+    def ref_forward(x):
+        h = x.reshape(x.shape[0], -1)
+        for lin in ref_layers[:-1]:
+            h = F.leaky_relu(lin(h), 0.2)
+        return ref_layers[-1](h).squeeze(-1)
+
+    x = torch.randn(300, 30, 2, device=DEV)
+    for call in range(2):  # two calls: the second starts from the advanced vectors
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        sa, sb = critic(xa), ref_forward(xb)
+        assert_close(sa, sb, 1e-5, msg=f"scores call {call}")
+        (ga,) = torch.autograd.grad(sa.sum(), xa, create_graph=True)
+        (gb,) = torch.autograd.grad(sb.sum(), xb, create_graph=True)
+        la = F.relu(1.0 - sa).mean() + ga.pow(2).sum(dim=(1, 2)).mean()
+        lb = F.relu(1.0 - sb).mean() + gb.pow(2).sum(dim=(1, 2)).mean()
+        for p in critic.parameters():
+            p.grad = None
+        for lin in ref_layers:
+            for p in lin.parameters():
+                p.grad = None
+        la.backward()
+        lb.backward()
+        for m, lin in zip(critic._spectral_layers(), ref_layers):
+            assert_close(m.weight_u, lin.weight_u, 1e-5, msg="u")
+            assert_close(m.weight_v, lin.weight_v, 1e-5, msg="v")
+            assert_close(m.weight_orig.grad, lin.weight_orig.grad, 2e-5, msg="d weight_orig")
+            assert_close(m.bias.grad, lin.bias.grad, 2e-5, msg="d bias")
+        assert_close(xa.grad, xb.grad, 2e-5, msg="d input")
