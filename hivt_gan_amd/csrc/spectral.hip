@@ -4,7 +4,7 @@
 //
 // The framework's hook (one per layer and per forward call) spends about a dozen tiny launches on
 // vectors of at most 256 entries; a critic is called nine times per training step.  Here one block
-// owns one layer: W (at most 256 x 256 floats) is read three times out of L2.
+// owns one layer: W (at most 512 x 512 floats) is read three times out of L2.
 #include "common.h"
 
 #include <math.h>
@@ -13,8 +13,9 @@ namespace hivt {
 namespace {
 
 constexpr int kMaxLayers = HIVT_SPECTRAL_MAX_LAYERS;
-constexpr int kMaxDim = 1024;  // rows / columns of one weight matrix (vectors live in LDS)
-constexpr int kThreads = 256;
+constexpr int kMaxDim = 512;  // rows / columns of one weight matrix (vectors and partial sums live in LDS)
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / kWave;
 
 struct SpectralArgs {
   const float* w[kMaxLayers];    // [rows, cols] row-major, un-normalised
@@ -49,15 +50,19 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   __syncthreads();
   float s = 0.0f;
 #pragma unroll
-  for (int w = 0; w < kThreads / kWave; ++w) s += red[w];
+  for (int w = 0; w < kWaves; ++w) s += red[w];
   return s;
 }
 
+// One workgroup of 16 waves per layer.  The matrix is streamed three times (W^T u, W v, W / sigma), a
+// wave taking whole rows so that its lanes read consecutive columns; rows are interleaved over the
+// waves and four rows are in flight per wave.
 __global__ __launch_bounds__(kThreads) void spectral_fwd_kernel(const SpectralArgs a) {
   __shared__ float su[kMaxDim];
   __shared__ float sv[kMaxDim];
   __shared__ float ss[kMaxDim];
-  __shared__ float red[kThreads / kWave];
+  __shared__ float part[kWaves][kMaxDim];
+  __shared__ float red[kWaves];
   const int L = blockIdx.x;
   const float* __restrict__ w = a.w[L];
   const int R = a.rows[L], C = a.cols[L];
@@ -68,11 +73,30 @@ __global__ __launch_bounds__(kThreads) void spectral_fwd_kernel(const SpectralAr
   __syncthreads();
 
   if (a.power_iteration) {
-    // v <- normalize(W^T u): thread per column, rows streamed (coalesced across threads)
+    // t = W^T u: every wave sums its rows into a private copy of t, the copies are added afterwards
+    for (int j0 = 0; j0 < C; j0 += kWave) {
+      const int j = j0 + lane;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+      if (j < C) {
+        int i = wave;
+        for (; i + 3 * kWaves < R; i += 4 * kWaves) {
+          const float a0 = w[(int64_t)i * C + j], a1 = w[(int64_t)(i + kWaves) * C + j];
+          const float a2 = w[(int64_t)(i + 2 * kWaves) * C + j], a3 = w[(int64_t)(i + 3 * kWaves) * C + j];
+          t0 = fmaf(a0, su[i], t0);
+          t1 = fmaf(a1, su[i + kWaves], t1);
+          t2 = fmaf(a2, su[i + 2 * kWaves], t2);
+          t3 = fmaf(a3, su[i + 3 * kWaves], t3);
+        }
+        for (; i < R; i += kWaves) t0 = fmaf(w[(int64_t)i * C + j], su[i], t0);
+        part[wave][j] = (t0 + t1) + (t2 + t3);
+      }
+    }
+    __syncthreads();
     float sq = 0.0f;
     for (int j = tid; j < C; j += kThreads) {
       float t = 0.0f;
-      for (int i = 0; i < R; ++i) t = fmaf(w[(int64_t)i * C + j], su[i], t);
+#pragma unroll
+      for (int q = 0; q < kWaves; ++q) t += part[q][j];
       sv[j] = t;
       sq = fmaf(t, t, sq);
     }
@@ -81,12 +105,20 @@ __global__ __launch_bounds__(kThreads) void spectral_fwd_kernel(const SpectralAr
     __syncthreads();
   }
 
-  // s = W v: one wave per row, lanes over columns
-  for (int i = wave; i < R; i += kThreads / kWave) {
-    float t = 0.0f;
-    for (int j = lane; j < C; j += kWave) t = fmaf(w[(int64_t)i * C + j], sv[j], t);
-    t = wave_sum(t);
-    if (lane == 0) ss[i] = t;
+  // s = W v: one wave per row, lanes over columns, two rows in flight
+  for (int i = wave; i < R; i += 2 * kWaves) {
+    const int i2 = i + kWaves;
+    float t0 = 0.0f, t1 = 0.0f;
+    for (int j = lane; j < C; j += kWave) {
+      t0 = fmaf(w[(int64_t)i * C + j], sv[j], t0);
+      if (i2 < R) t1 = fmaf(w[(int64_t)i2 * C + j], sv[j], t1);
+    }
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    if (lane == 0) {
+      ss[i] = t0;
+      if (i2 < R) ss[i2] = t1;
+    }
   }
   __syncthreads();
 
@@ -113,29 +145,57 @@ __global__ __launch_bounds__(kThreads) void spectral_fwd_kernel(const SpectralAr
   if (tid == 0) a.sigma[L] = sigma;
   const int64_t total = (int64_t)R * C;
   float* __restrict__ wn = a.wn[L];
-  for (int64_t e = tid; e < total; e += kThreads) wn[e] = w[e] / sigma;
+  if ((total & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(wn)) & 15) == 0) {
+    for (int64_t e = tid; e < total / 4; e += kThreads) {
+      const float4 x = reinterpret_cast<const float4*>(w)[e];
+      reinterpret_cast<float4*>(wn)[e] = make_float4(x.x / sigma, x.y / sigma, x.z / sigma, x.w / sigma);
+    }
+  } else {
+    for (int64_t e = tid; e < total; e += kThreads) wn[e] = w[e] / sigma;
+  }
 }
 
 // wn = w / sigma, sigma = u^T w v with u, v constants:
 //   d_w = d_wn / sigma - (<d_wn, w> / sigma^2) u v^T
 __global__ __launch_bounds__(kThreads) void spectral_bwd_kernel(const SpectralBwdArgs a) {
-  __shared__ float red[kThreads / kWave];
+  __shared__ float red[kWaves];
   const int L = blockIdx.x;
   const int R = a.rows[L], C = a.cols[L];
   const float* __restrict__ g = a.d_wn[L];
   const float* __restrict__ w = a.w[L];
-  const int64_t total = (int64_t)R * C;
-  float acc = 0.0f;
-  for (int64_t e = threadIdx.x; e < total; e += kThreads) acc = fmaf(g[e], w[e], acc);
-  const float sigma = a.sigma[L];
-  const float coef = block_sum(acc, red) / (sigma * sigma);
-  const float inv = 1.0f / sigma;
   const float* __restrict__ u = a.u_used[L];
   const float* __restrict__ v = a.v_used[L];
   float* __restrict__ d = a.d_w[L];
-  for (int64_t e = threadIdx.x; e < total; e += kThreads) {
-    const int i = (int)(e / C), j = (int)(e - (int64_t)i * C);
-    d[e] = g[e] * inv - coef * u[i] * v[j];
+  const int64_t total = (int64_t)R * C;
+  const bool vec = (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(w) |
+                                     reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  float acc = 0.0f;
+  if (vec) {
+    for (int64_t e = threadIdx.x; e < total / 4; e += kThreads) {
+      const float4 x = reinterpret_cast<const float4*>(g)[e], y = reinterpret_cast<const float4*>(w)[e];
+      acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+  } else {
+    for (int64_t e = threadIdx.x; e < total; e += kThreads) acc = fmaf(g[e], w[e], acc);
+  }
+  const float sigma = a.sigma[L];
+  const float coef = block_sum(acc, red) / (sigma * sigma);
+  const float inv = 1.0f / sigma;
+  if (vec) {
+    const int c4 = C / 4;
+    for (int64_t e = threadIdx.x; e < total / 4; e += kThreads) {
+      const int i = (int)(e / c4), j4 = (int)(e - (int64_t)i * c4);
+      const float4 x = reinterpret_cast<const float4*>(g)[e];
+      const float4 vv = reinterpret_cast<const float4*>(v)[j4];
+      const float cu = coef * u[i];
+      reinterpret_cast<float4*>(d)[e] =
+          make_float4(x.x * inv - cu * vv.x, x.y * inv - cu * vv.y, x.z * inv - cu * vv.z, x.w * inv - cu * vv.w);
+    }
+  } else {
+    for (int64_t e = threadIdx.x; e < total; e += kThreads) {
+      const int i = (int)(e / C), j = (int)(e - (int64_t)i * C);
+      d[e] = g[e] * inv - coef * u[i] * v[j];
+    }
   }
 }
 

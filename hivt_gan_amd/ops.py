@@ -605,6 +605,18 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def _aligned_parts(buf: torch.Tensor, sizes):
+    parts, off = [], 0
+    for n in sizes:
+        parts.append(buf[off:off + n])
+        off += _round4(n)
+    return parts
+
+
 class _SpectralNormalize(torch.autograd.Function):
     """``(w_0 / sigma_0, ..., w_{L-1} / sigma_{L-1})`` for L weight matrices in one launch; in training
     mode one power iteration updates the ``u`` / ``v`` buffers in place first."""
@@ -619,10 +631,10 @@ class _SpectralNormalize(torch.autograd.Function):
         rows = (ctypes.c_int32 * layers)(*[w.shape[0] for w in ws])
         cols = (ctypes.c_int32 * layers)(*[w.shape[1] for w in ws])
         wn = [torch.empty_like(w) for w in ws]
-        # one buffer for every layer's copies of u and v
+        # one buffer for every layer's copies of u and v, each 16-byte aligned
         sizes = [w.shape[0] for w in ws] + [w.shape[1] for w in ws]
-        used = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        parts = list(torch.split(used, sizes))
+        used = torch.empty(sum(_round4(n) for n in sizes), dtype=torch.float32, device=dev)
+        parts = _aligned_parts(used, sizes)
         u_used, v_used = parts[:layers], parts[layers:]
         sigma = torch.empty(layers, dtype=torch.float32, device=dev)
         _lib.call("hivt_spectral_norm_fwd", layers, _ptr_array(ws), _ptr_array(us), _ptr_array(vs), rows, cols,
@@ -637,7 +649,7 @@ class _SpectralNormalize(torch.autograd.Function):
     def backward(ctx, *d_wn):
         used, sigma, *ws = ctx.saved_tensors
         layers = len(ws)
-        parts = list(torch.split(used, ctx.sizes))
+        parts = _aligned_parts(used, ctx.sizes)
         u_used, v_used = parts[:layers], parts[layers:]
         keep = [i for i, g in enumerate(d_wn) if g is not None]
         grads = [None] * layers

@@ -302,7 +302,7 @@ int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const
  * normalize(x) = x / max(||x||_2, eps).  w[l] is float [rows[l], cols[l]] row-major, u[l] [rows[l]],
  * v[l] [cols[l]].  u_used / v_used receive the vectors sigma was formed with; they are the constants of
  * the gradient (the hook clones u and v for the same purpose).  The pointer arrays and rows / cols are
- * HOST arrays of `layers` entries; each side of a matrix is at most 1024. */
+ * HOST arrays of `layers` entries; each side of a matrix is at most 512. */
 int hivt_spectral_norm_fwd(int32_t layers, const float* const* w, float* const* u, float* const* v,
                            const int32_t* rows, const int32_t* cols, int32_t power_iteration, float eps,
                            float* const* wn, float* const* u_used, float* const* v_used, float* sigma,
