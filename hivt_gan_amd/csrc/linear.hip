@@ -131,16 +131,21 @@ struct Core {
   static constexpr int LDS_FLOATS = STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS;
   static constexpr int WN = BN / 64;  // waves along the columns; each wave owns 32 x 64
 
-  // Accumulates the product over [red_begin, red_end) and leaves the BM x BN tile in lds as
-  // C[row][col] (pitch C_PITCH).  All threads of the block must call it.
+  // Accumulates the product over [red_begin, red_end) into the calling wave's two 32x32 accumulators
+  // (rows wr*32.., columns wc*64.. and wc*64+32..).  All threads of the block must call it.
   // With ACC_A, *a_colsum receives this thread's sum of the operand-A values it staged.
-  __device__ static void run(const Operand& a, const Operand& b, int row0, int col0, int red_begin, int red_end,
-                             float* lds, float4* a_colsum = nullptr) {
+  __device__ static void accumulate(const Operand& a, const Operand& b, int row0, int col0, int red_begin,
+                                    int red_end, float* lds, f32x16& acc0, f32x16& acc1,
+                                    float4* a_colsum = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int lo = lane & 31, hi = lane >> 5;
-    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.0f;
+      acc1[r] = 0.0f;
+    }
     SA sa;
     SB sb;
     // buffer b of operand A starts at b * BUF, of operand B at b * BUF + A_FLOATS (plain integer
@@ -178,7 +183,14 @@ struct Core {
       __syncthreads();
     }
     if (ACC_A) *a_colsum = sa.colsum;
-    // accumulators -> LDS tile (the staging buffers are dead after the last barrier)
+  }
+
+  // accumulators -> LDS tile C[row][col] (pitch C_PITCH); the staging buffers are dead after the last
+  // barrier of accumulate().  Ends with a barrier.
+  __device__ static void spill(float* lds, const f32x16& acc0, const f32x16& acc1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int lo = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -186,6 +198,39 @@ struct Core {
       lds[row * C_PITCH + wc * 64 + 32 + lo] = acc1[r];
     }
     __syncthreads();
+  }
+
+  // accumulators -> global memory without the LDS round trip: for a fixed register the 32 low lanes
+  // hold 32 consecutive columns of one row (a 128-byte segment) and the high lanes the row 4 below.
+  // out = [relu](acc + bias[col] + add[row][col]); bias / add may be null.
+  template <bool RELU>
+  __device__ static void store_direct(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
+                                      float* __restrict__ out, int64_t out_ld, const float* __restrict__ bias,
+                                      const float* __restrict__ add, int64_t add_ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int c0 = col0 + wc * 64 + lo, c1 = c0 + 32;
+    const bool ok0 = c0 < cols, ok1 = c1 < cols;
+    const float b0 = (bias != nullptr && ok0) ? bias[c0] : 0.0f;
+    const float b1 = (bias != nullptr && ok1) ? bias[c1] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gr = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (gr < rows) {
+        float v0 = acc0[r] + b0, v1 = acc1[r] + b1;
+        if (add != nullptr) {
+          if (ok0) v0 += add[(int64_t)gr * add_ld + c0];
+          if (ok1) v1 += add[(int64_t)gr * add_ld + c1];
+        }
+        if (RELU) {
+          v0 = fmaxf(v0, 0.0f);
+          v1 = fmaxf(v1, 0.0f);
+        }
+        if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
+        if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
+      }
+    }
   }
 };
 
@@ -214,52 +259,79 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   Operand xa = a.x, wa = a.w;
-  C::run(xa, wa, row0, col0, 0, a.x.red, lds);
+  f32x16 acc0, acc1;
+  C::accumulate(xa, wa, row0, col0, 0, a.x.red, lds, acc0, acc1);
+  if (EPI == EPI_NONE || EPI == EPI_RELU) {
+    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.bias, a.add, a.add_ld);
+    return;
+  }
+  // LayerNorm over the full output row: the row is spread over the waves, so it goes through LDS;
+  // a wave then owns whole rows, two at a time, with the per-column constants held in registers.
+  C::spill(lds, acc0, acc1);
+  constexpr int CPL = BN / 64;  // columns per lane: lane, lane + 64
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < BM; r += 4) {
-    const int gr = row0 + r;
-    if (gr >= a.M) break;
-    float vals[BN / 64];
-    float sum = 0.0f;
+  float bias[CPL], gam[CPL], bet[CPL];
+  bool okc[CPL];
 #pragma unroll
-    for (int j = 0; j < BN / 64; ++j) {
-      const int c = lane + 64 * j, gc = col0 + c;
-      float v = 0.0f;
-      if (gc < a.N) {
-        v = lds[r * C::C_PITCH + c] + (a.bias ? a.bias[gc] : 0.0f);
-        if (a.add) v += a.add[(int64_t)gr * a.add_ld + gc];
+  for (int j = 0; j < CPL; ++j) {
+    const int gc = col0 + lane + 64 * j;
+    okc[j] = gc < a.N;
+    bias[j] = (okc[j] && a.bias != nullptr) ? a.bias[gc] : 0.0f;
+    gam[j] = okc[j] ? a.gamma[gc] : 0.0f;
+    bet[j] = okc[j] ? a.beta[gc] : 0.0f;
+  }
+  const float inv_n = 1.0f / (float)a.N;
+  for (int r = wave; r < BM; r += 8) {
+    constexpr int U = 2;  // rows r and r + 4 together: two independent reduction chains
+    float vals[U][CPL], sum[U];
+    bool okr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + 4 * u, gr = row0 + rr;
+      okr[u] = rr < BM && gr < a.M;
+      sum[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        float v = 0.0f;
+        if (okr[u] && okc[j]) {
+          v = lds[rr * C::C_PITCH + lane + 64 * j] + bias[j];
+          if (a.add) v += a.add[(int64_t)gr * a.add_ld + col0 + lane + 64 * j];
+        }
+        vals[u][j] = v;
+        sum[u] += v;
       }
-      vals[j] = v;
-      sum += v;
     }
-    if (EPI == EPI_LN || EPI == EPI_LN_RELU) {
-      const float mean = wave_sum(sum) / (float)a.N;
+    float mean[U], rstd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mean[u] = wave_sum(sum[u]) * inv_n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
       float sq = 0.0f;
 #pragma unroll
-      for (int j = 0; j < BN / 64; ++j) {
-        const float d = (col0 + lane + 64 * j < a.N) ? vals[j] - mean : 0.0f;
+      for (int j = 0; j < CPL; ++j) {
+        const float d = okc[j] ? vals[u][j] - mean[u] : 0.0f;
         sq += d * d;
       }
-      const float rstd = rsqrtf(wave_sum(sq) / (float)a.N + a.eps);
+      sum[u] = sq;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) rstd[u] = rsqrtf(wave_sum(sum[u]) * inv_n + a.eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!okr[u]) continue;
+      const int64_t gr = row0 + r + 4 * u;
       if (lane == 0 && a.stats) {
-        a.stats[2 * (int64_t)gr] = mean;
-        a.stats[2 * (int64_t)gr + 1] = rstd;
+        a.stats[2 * gr] = mean[u];
+        a.stats[2 * gr + 1] = rstd[u];
       }
 #pragma unroll
-      for (int j = 0; j < BN / 64; ++j) {
+      for (int j = 0; j < CPL; ++j) {
+        if (!okc[j]) continue;
         const int gc = col0 + lane + 64 * j;
-        if (gc < a.N) {
-          if (a.z) a.z[(int64_t)gr * a.z_ld + gc] = vals[j];
-          float o = (vals[j] - mean) * rstd * a.gamma[gc] + a.beta[gc];
-          if (EPI == EPI_LN_RELU) o = fmaxf(o, 0.0f);
-          a.y[(int64_t)gr * a.y_ld + gc] = o;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < BN / 64; ++j) {
-        const int gc = col0 + lane + 64 * j;
-        if (gc < a.N) a.y[(int64_t)gr * a.y_ld + gc] = (EPI == EPI_RELU) ? fmaxf(vals[j], 0.0f) : vals[j];
+        if (a.z) a.z[gr * a.z_ld + gc] = vals[u][j];
+        float o = (vals[u][j] - mean[u]) * rstd[u] * gam[j] + bet[j];
+        if (EPI == EPI_LN_RELU) o = fmaxf(o, 0.0f);
+        a.y[gr * a.y_ld + gc] = o;
       }
     }
   }
@@ -280,17 +352,9 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   using C = Core<BM, BN, true, false, VEC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
-  C::run(a.dy, a.w, row0, col0, 0, a.dy.red, lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < BM; r += 4) {
-    const int gr = row0 + r;
-    if (gr >= a.M) break;
-#pragma unroll
-    for (int j = 0; j < BN / 64; ++j) {
-      const int c = lane + 64 * j, gc = col0 + c;
-      if (gc < a.K) a.dx[(int64_t)gr * a.dx_ld + gc] = lds[r * C::C_PITCH + c];
-    }
-  }
+  f32x16 acc0, acc1;
+  C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
+  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, nullptr, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,7 +380,9 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   dy.red = m_end;
   x.red = m_end;
   float4 colsum;
-  C::run(dy, x, row0, col0, m_begin, m_end, lds, &colsum);
+  f32x16 acc0, acc1;
+  C::accumulate(dy, x, row0, col0, m_begin, m_end, lds, acc0, acc1, &colsum);
+  C::spill(lds, acc0, acc1);
   float* out = a.partial + (int64_t)chunk * a.N * a.K;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = wave; r < BM; r += 4) {
@@ -350,8 +416,10 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
 // out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: four row slices are summed
 // independently (ascending r inside a slice) and then combined in slice order, so the result does
 // not depend on scheduling.  One block covers 64 columns; each thread sums one slice of one column.
+// Columns at or beyond `split` go to out1[c - split] (two result vectors from one partial buffer).
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
-                                                          int C, float* __restrict__ out) {
+                                                          int C, float* __restrict__ out, int split = 0x7fffffff,
+                                                          float* __restrict__ out1 = nullptr) {
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int sl = threadIdx.x >> 6;
@@ -371,7 +439,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   }
   part[sl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (sl == 0 && c < C) out[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+  if (sl == 0 && c < C) {
+    const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (c < split)
+      out[c] = t;
+    else
+      out1[c - split] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +461,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int relu, int64_t M, int N, int vec, float* __restrict__ dz,
                                                      int64_t dz_ld, float* __restrict__ partial /*[grid][2][N]*/) {
   __shared__ float red[4][2][64 * NPL];
+  constexpr int U = 2;  // rows in flight per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * NPL;
   float g_[NPL], b_[NPL], dg[NPL], db[NPL];
@@ -399,46 +474,67 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
   const float inv_n = 1.0f / (float)N;
   const bool full = vec && (c0 + NPL <= N);
-  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
-    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-    float zz[NPL], dd[NPL];
-    if (NPL == 2 && full) {
-      const float2 a = *reinterpret_cast<const float2*>(z + r * z_ld + c0);
-      const float2 b = *reinterpret_cast<const float2*>(dy + r * dy_ld + c0);
-      zz[0] = a.x; zz[NPL - 1] = a.y; dd[0] = b.x; dd[NPL - 1] = b.y;
-    } else {
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4 + wave; r0 < M; r0 += U * stride) {
+    float zz[U][NPL], dd[U][NPL], mean[U], rstd[U];
+    bool okr[U];
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        zz[j] = c0 + j < N ? z[r * z_ld + c0 + j] : 0.0f;
-        dd[j] = c0 + j < N ? dy[r * dy_ld + c0 + j] : 0.0f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * stride;
+      okr[u] = r < M;
+      const int64_t rc = okr[u] ? r : r0;
+      mean[u] = stats[2 * rc];
+      rstd[u] = stats[2 * rc + 1];
+      if (NPL == 2 && full) {
+        const float2 a = *reinterpret_cast<const float2*>(z + rc * z_ld + c0);
+        const float2 b = *reinterpret_cast<const float2*>(dy + rc * dy_ld + c0);
+        zz[u][0] = a.x; zz[u][NPL - 1] = a.y; dd[u][0] = b.x; dd[u][NPL - 1] = b.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+          zz[u][j] = c0 + j < N ? z[rc * z_ld + c0 + j] : 0.0f;
+          dd[u][j] = c0 + j < N ? dy[rc * dy_ld + c0 + j] : 0.0f;
+        }
       }
     }
-    float xh[NPL], gg[NPL];
-    float s1 = 0.0f, s2 = 0.0f;
+    float xh[U][NPL], gg[U][NPL], s1[U], s2[U];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const bool in = c0 + j < N;
-      const float x = in ? (zz[j] - mean) * rstd : 0.0f;
-      float d = in ? dd[j] : 0.0f;
-      if (relu && !(x * g_[j] + b_[j] > 0.0f)) d = 0.0f;
-      xh[j] = x;
-      dg[j] += d * x;
-      db[j] += d;
-      gg[j] = d * g_[j];
-      s1 += gg[j];
-      s2 += gg[j] * x;
+    for (int u = 0; u < U; ++u) {
+      s1[u] = 0.0f;
+      s2[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const bool in = okr[u] && c0 + j < N;
+        const float x = in ? (zz[u][j] - mean[u]) * rstd[u] : 0.0f;
+        float d = in ? dd[u][j] : 0.0f;
+        if (relu && !(x * g_[j] + b_[j] > 0.0f)) d = 0.0f;
+        xh[u][j] = x;
+        dg[j] += d * x;
+        db[j] += d;
+        gg[u][j] = d * g_[j];
+        s1[u] += gg[u][j];
+        s2[u] += gg[u][j] * x;
+      }
     }
-    s1 = wave_sum(s1) * inv_n;
-    s2 = wave_sum(s2) * inv_n;
-    float o[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) o[j] = rstd * (gg[j] - s1 - xh[j] * s2);
-    if (NPL == 2 && full) {
-      *reinterpret_cast<float2*>(dz + r * dz_ld + c0) = make_float2(o[0], o[NPL - 1]);
-    } else {
+    for (int u = 0; u < U; ++u) {
+      s1[u] = wave_sum(s1[u]) * inv_n;
+      s2[u] = wave_sum(s2[u]) * inv_n;
+    }
 #pragma unroll
-      for (int j = 0; j < NPL; ++j)
-        if (c0 + j < N) dz[r * dz_ld + c0 + j] = o[j];
+    for (int u = 0; u < U; ++u) {
+      if (!okr[u]) continue;
+      const int64_t r = r0 + u * stride;
+      float o[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) o[j] = rstd[u] * (gg[u][j] - s1[u] - xh[u][j] * s2[u]);
+      if (NPL == 2 && full) {
+        *reinterpret_cast<float2*>(dz + r * dz_ld + c0) = make_float2(o[0], o[NPL - 1]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+          if (c0 + j < N) dz[r * dz_ld + c0 + j] = o[j];
+      }
     }
   }
 #pragma unroll
@@ -451,6 +547,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int which = i / N, c = i % N;
     partial[((int64_t)blockIdx.x * 2 + which) * N + c] =
         ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+  }
+}
+
+// Stand-alone LayerNorm forward: y = gamma * (x - mean) * rstd + beta, one wave per row, two rows in
+// flight; mean / rstd are kept for the backward pass (two-pass variance, as in the fused epilogue).
+template <int NPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, int64_t M, int N, int vec, float* __restrict__ y,
+                                                     int64_t y_ld, float* __restrict__ stats) {
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * NPL;
+  float g_[NPL], b_[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    g_[j] = c0 + j < N ? gamma[c0 + j] : 0.0f;
+    b_[j] = c0 + j < N ? beta[c0 + j] : 0.0f;
+  }
+  const float inv_n = 1.0f / (float)N;
+  const bool full = vec && (c0 + NPL <= N);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = (int64_t)blockIdx.x * 4 + wave; r0 < M; r0 += U * stride) {
+    float v[U][NPL], s[U], mean[U];
+    bool okr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * stride;
+      okr[u] = r < M;
+      const int64_t rc = okr[u] ? r : r0;
+      if (NPL == 2 && full) {
+        const float2 a = *reinterpret_cast<const float2*>(x + rc * x_ld + c0);
+        v[u][0] = a.x; v[u][NPL - 1] = a.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) v[u][j] = c0 + j < N ? x[rc * x_ld + c0 + j] : 0.0f;
+      }
+      s[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) s[u] += v[u][j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mean[u] = wave_sum(s[u]) * inv_n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float sq = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const float d = c0 + j < N ? v[u][j] - mean[u] : 0.0f;
+        sq += d * d;
+      }
+      s[u] = sq;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = rsqrtf(wave_sum(s[u]) * inv_n + eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!okr[u]) continue;
+      const int64_t r = r0 + u * stride;
+      if (lane == 0) {
+        stats[2 * r] = mean[u];
+        stats[2 * r + 1] = s[u];
+      }
+      float o[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) o[j] = (v[u][j] - mean[u]) * s[u] * g_[j] + b_[j];
+      if (NPL == 2 && full) {
+        *reinterpret_cast<float2*>(y + r * y_ld + c0) = make_float2(o[0], o[NPL - 1]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+          if (c0 + j < N) y[r * y_ld + c0 + j] = o[j];
+      }
+    }
   }
 }
 
@@ -646,11 +816,30 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
     hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
                        beta, relu, M, N, vec, dz, dz_ld, partial);
   HIVT_CHECK_LAUNCH(what);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial, (int)blocks,
-                     (int64_t)2 * N, N, dgamma);
+  // partial is [blocks][2][N]: one reduction over the 2N columns, first half -> dgamma, second -> dbeta
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((2 * N + 63) / 64)), dim3(256), 0, s, partial, (int)blocks,
+                     (int64_t)2 * N, 2 * N, dgamma, N, dbeta);
   HIVT_CHECK_LAUNCH(what);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, partial + N, (int)blocks,
-                     (int64_t)2 * N, N, dbeta);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_ln_fwd(const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps, int64_t M,
+                           int32_t N, float* y, int64_t y_ld, float* stats, hivt_stream_t stream) {
+  const char* what = "hivt_ln_fwd";
+  HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128, HIVT_ERR_ARG, "%s: N must be in [1,128] (N=%d)", what, N);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(x && gamma && beta && y && stats, HIVT_ERR_ARG, "%s: null pointer", what);
+  int64_t blocks = (M + 7) / 8;
+  if (blocks > 2048) blocks = 2048;
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  const int vec = (al8(x) && al8(y) && x_ld % 2 == 0 && y_ld % 2 == 0) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64)
+    hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, gamma, beta, eps, M, N, vec,
+                       y, y_ld, stats);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, gamma, beta, eps, M, N, vec,
+                       y, y_ld, stats);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

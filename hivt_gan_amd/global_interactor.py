@@ -50,8 +50,8 @@ class GlobalInteractorLayer(nn.Module):
             edges = _edge_set_from_coo(edge_index, edge_attr.new_zeros(edge_attr.shape[0], 2), x.shape[0], x.shape[0])
             edges.src = edges.coo_src.index_select(0, edges.perm.long())
             edge_attr = edge_attr.index_select(0, edges.perm.long())
-        x = x + self._mha_block(self.norm1(x), edges, edge_attr)
-        x = x + self._ff_block(self.norm2(x))
+        x = x + self._mha_block(ops.layer_norm(x, self.norm1), edges, edge_attr)
+        x = x + self._ff_block(ops.layer_norm(x, self.norm2))
         return x
 
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor) -> torch.Tensor:
@@ -109,6 +109,6 @@ class GlobalInteractor(nn.Module):
         x = local_embed
         for layer in self.global_interactor_layers:
             x = layer(x, None, rel_embed, edges=edges)
-        x = self.norm(x)
+        x = ops.layer_norm(x, self.norm)
         x = self.multihead_proj(x).view(-1, self.num_modes, self.embed_dim)
         return x.transpose(0, 1)

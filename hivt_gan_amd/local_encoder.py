@@ -188,8 +188,8 @@ class AAEncoder(_EdgeAttentionBase):
             rot_mod = x.shape[0]
         if edges is None:
             edges = _edge_set_from_coo(edge_index, edge_attr, x.shape[0], x.shape[0])
-        center = center + self._mha_block(self.norm1(center), x, edges, rotate_mat, rot_mod)
-        center = center + self._ff_block(self.norm2(center))
+        center = center + self._mha_block(ops.layer_norm(center, self.norm1), x, edges, rotate_mat, rot_mod)
+        center = center + self._ff_block(ops.layer_norm(center, self.norm2))
         return center
 
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
@@ -222,8 +222,8 @@ class ALEncoder(_EdgeAttentionBase):
             edges = _edge_set_from_coo(edge_index, edge_attr, x_lane.shape[0], x_actor.shape[0])
         # one code per lane for the three categorical attributes, one table row per code
         code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
-        x_actor = x_actor + self._mha_block(self.norm1(x_actor), x_lane, edges, code, rotate_mat)
-        x_actor = x_actor + self._ff_block(self.norm2(x_actor))
+        x_actor = x_actor + self._mha_block(ops.layer_norm(x_actor, self.norm1), x_lane, edges, code, rotate_mat)
+        x_actor = x_actor + self._ff_block(ops.layer_norm(x_actor, self.norm2))
         return x_actor
 
     def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
@@ -280,8 +280,8 @@ class TemporalEncoderLayer(nn.Module):
 
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
-        x = src + self._sa_block(self.norm1(src))
-        return x + self.dropout2(self._ff(self.norm2(x)))
+        x = src + self._sa_block(ops.layer_norm(src, self.norm1))
+        return x + self.dropout2(self._ff(ops.layer_norm(x, self.norm2)))
 
 
 class _EncoderStack(nn.Module):
@@ -295,7 +295,7 @@ class _EncoderStack(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         for layer in self.layers:
             x = layer(x)
-        return self.norm(x)
+        return ops.layer_norm(x, self.norm)
 
 
 class TemporalEncoder(nn.Module):

@@ -514,7 +514,7 @@ class _FusedLinear(torch.autograd.Function):
             _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), n, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
                       _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
         elif relu:
-            dz = dy2 * (y_relu > 0)
+            dz = torch.ops.aten.threshold_backward(dy2, y_relu, 0.0)  # dy where y > 0, one launch
         else:
             dz = dy2
         dx = dw = db = None
@@ -530,6 +530,47 @@ class _FusedLinear(torch.autograd.Function):
                       _p(ws), ws.numel(), s)
         dadd = dz.view(add_shape) if (has_add and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dadd, dgamma, dbeta, None, None
+
+
+class _LayerNorm(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x, gamma, beta)
+        lead = x.shape[:-1]
+        x2 = _rows2(x)
+        m, n = x2.shape
+        gamma_c, beta_c = gamma.contiguous(), beta.contiguous()
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        stats = torch.empty(m, 2, dtype=torch.float32, device=x.device)
+        _lib.call("hivt_ln_fwd", _p(x2), x2.stride(0), _p(gamma_c), _p(beta_c), float(eps), m, n, _p(y), n, _p(stats),
+                  _stream(x))
+        ctx.save_for_backward(x2, stats, gamma_c, beta_c)
+        ctx.lead = tuple(lead)
+        return y.view(*lead, n)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, stats, gamma, beta = ctx.saved_tensors
+        m, n = x2.shape
+        dev = x2.device
+        dy2 = _rows2(dy)
+        dx = torch.empty(m, n, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
+        _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, n,
+                  _p(dx), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream(x2))
+        return dx.view(*ctx.lead, n), dgamma, dbeta, None
+
+
+def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
+    """``norm(x)`` over the last dimension on the streaming LayerNorm kernels (width <= 128); wider rows
+    and CPU tensors go to the framework's implementation."""
+    if not x.is_cuda or x.shape[-1] > 128 or x.dtype != torch.float32 or x.numel() == 0:
+        return norm(x)
+    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
 
 
 def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,

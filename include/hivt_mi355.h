@@ -229,6 +229,13 @@ int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_
                       int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                       hivt_stream_t stream);
 
+/* Stand-alone LayerNorm forward over the last dimension (N <= 128): y = gamma * (x - mean) * rstd + beta,
+ * stats float [M,2] = (mean, rstd) per row for hivt_ln_bwd (called with z = x, relu = 0).  Replaces the
+ * nn.LayerNorm in front of the attention and feed-forward blocks (models/local_encoder.py:119-120,
+ * 166-167, 254-255; models/global_interactor.py:92-93,107-108). */
+int hivt_ln_fwd(const float* x, int64_t x_ld, const float* gamma, const float* beta, float eps, int64_t M, int32_t N,
+                float* y, int64_t y_ld, float* stats, hivt_stream_t stream);
+
 /* Workspace for hivt_ln_bwd. */
 size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N);
 

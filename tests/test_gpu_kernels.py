@@ -530,3 +530,29 @@ def test_temporal_attention_dropout_mask_consistency():
     assert torch.isfinite(qkv.grad).all()
     assert torch.allclose(ops.temporal_attention(qkv.detach(), H, dropout_p=p, training=False),
                           torch.ones(S, N, D, device=DEV), atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(1, 128), (5, 64), (1000, 128), (21, 300, 128), (4097, 100), (333, 7)])
+def test_layer_norm_kernel_vs_framework(shape):
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=gen) * 3 + 1).to(DEV).requires_grad_(True)
+    norm = torch.nn.LayerNorm(shape[-1]).to(DEV)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(shape[-1], generator=gen))
+        norm.bias.copy_(torch.randn(shape[-1], generator=gen))
+    go = torch.randn(*shape, generator=gen).to(DEV)
+    y = ops.layer_norm(x, norm)
+    gx, gw, gb = torch.autograd.grad(y, (x, norm.weight, norm.bias), go)
+    xr = x.detach().double().requires_grad_(True)
+    wr, br = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (shape[-1],), wr, br, norm.eps)
+    rx, rw, rb = torch.autograd.grad(yr, (xr, wr, br), go.double())
+    close(y, yr.float(), 1e-5)
+    close(gx, rx.float(), 1e-5)
+    close(gw, rw.float(), 2e-5)
+    close(gb, rb.float(), 2e-5)
+    # a strided view (every other row of a wider buffer) goes through the same kernels
+    if len(shape) == 2 and shape[0] > 1:
+        wide = torch.randn(shape[0], 2 * shape[1], generator=gen).to(DEV)
+        view = wide[:, :shape[1]]
+        close(ops.layer_norm(view, norm), norm(view), 1e-5)
