@@ -57,6 +57,10 @@ SIGNATURES = {
                                          _P, c_size_t, _P]),
     "hivt_laplace_minmode_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P,
                                          _P, _P, _P]),
+    "hivt_embed2_fwd": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P]),
+    "hivt_embed2_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "hivt_embed2_bwd": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P, _P,
+                                c_size_t, _P]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -56,6 +56,9 @@ inline void zero_words(void* p, int64_t words, hipStream_t stream) {
                      words);
 }
 
+// out[c] = sum over r < rows of partial[r * cols + c], summed in a fixed order (deterministic).
+void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream);
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -649,6 +649,12 @@ int pick_chunks(int64_t M, int tiles) {
 }
 
 }  // namespace
+
+void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, partial, rows,
+                     (int64_t)cols, cols, out, 0x7fffffff, (float*)nullptr);
+}
+
 }  // namespace hivt
 
 using namespace hivt;

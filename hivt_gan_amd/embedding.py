@@ -66,7 +66,10 @@ class SingleInputEmbedding(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         e = self.embed  # Linear, LN, ReLU, Linear, LN, ReLU, Linear, LN -> three fused launches
-        h = ops.fused_linear(x, e[0].weight, e[0].bias, layer_norm=e[1], relu=True)
+        if x.is_cuda and ops.embed2_supported([e[0].in_features], e[0].out_features):
+            h = ops.embed2(x, [(e[0].weight, e[0].bias, e[1].weight, e[1].bias)], e[1].eps)
+        else:
+            h = ops.fused_linear(x, e[0].weight, e[0].bias, layer_norm=e[1], relu=True)
         h = ops.fused_linear(h, e[3].weight, e[3].bias, layer_norm=e[4], relu=True)
         return ops.fused_linear(h, e[6].weight, e[6].bias, layer_norm=e[7], relu=False)
 
@@ -83,15 +86,24 @@ class MultipleInputEmbedding(nn.Module):
                                         nn.Linear(out_channel, out_channel), nn.LayerNorm(out_channel))
         self.apply(init_weights)
 
-    def _fuse(self, branch_inputs: Sequence[torch.Tensor], extra: Optional[torch.Tensor]) -> torch.Tensor:
-        """Branch first layers (Linear+LN+ReLU, one launch each), then ALL second linears as one
-        product over the concatenated hidden rows ([h_0 | h_1 | ..] @ [W_0 | W_1 | ..]^T + sum of
-        biases, which equals the sum of the branch outputs), the categorical rows added in the same
-        epilogue as LN+ReLU, then Linear+LN."""
-        hidden = [ops.fused_linear(inp, br[0].weight, br[0].bias, layer_norm=br[1], relu=True)
-                  for br, inp in zip(self.module_list, branch_inputs)]
-        h = hidden[0] if len(hidden) == 1 else torch.cat(hidden, dim=-1)
-        weight = self.module_list[0][3].weight if len(hidden) == 1 else \
+    def _fuse(self, branch_inputs: Sequence[torch.Tensor], extra: Optional[torch.Tensor],
+              packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Branch first layers (Linear+LN+ReLU; one streaming launch for all branches when every input
+        has two components, else one launch each), then ALL second linears as one product over the
+        concatenated hidden rows ([h_0 | h_1 | ..] @ [W_0 | W_1 | ..]^T + sum of biases, which equals
+        the sum of the branch outputs), the categorical rows added in the same epilogue as LN+ReLU,
+        then Linear+LN.  ``packed`` holds the inputs side by side if the caller has them that way."""
+        width = self.module_list[0][0].out_features
+        if branch_inputs[0].is_cuda and ops.embed2_supported(self.in_channels, width):
+            if packed is None:
+                packed = branch_inputs[0] if len(branch_inputs) == 1 else torch.cat(list(branch_inputs), dim=-1)
+            h = ops.embed2(packed, [(br[0].weight, br[0].bias, br[1].weight, br[1].bias) for br in self.module_list],
+                           self.module_list[0][1].eps)
+        else:
+            hidden = [ops.fused_linear(inp, br[0].weight, br[0].bias, layer_norm=br[1], relu=True)
+                      for br, inp in zip(self.module_list, branch_inputs)]
+            h = hidden[0] if len(hidden) == 1 else torch.cat(hidden, dim=-1)
+        weight = self.module_list[0][3].weight if len(self.module_list) == 1 else \
             torch.cat([br[3].weight for br in self.module_list], dim=1)
         bias = self.module_list[0][3].bias
         for br in self.module_list[1:]:
@@ -116,4 +128,4 @@ class MultipleInputEmbedding(nn.Module):
         for width in self.in_channels:
             parts.append(packed[:, col:col + width])
             col += width
-        return self._fuse(parts, categorical_sum)
+        return self._fuse(parts, categorical_sum, packed if col == packed.shape[-1] else None)

@@ -721,3 +721,70 @@ def spectral_normalize(weights, us, vs, training: bool, eps: float = 1e-12):
             raise TypeError("spectral_normalize needs float32 weights and contiguous u / v")
     _need_gpu(*us, *vs)
     return _SpectralNormalize.apply((list(us), list(vs), bool(training), eps), *weights)
+
+
+# --------------------------------------------------------------------------------------------
+# First stage of the embedding MLPs (two-component inputs)
+# --------------------------------------------------------------------------------------------
+def embed2_supported(in_channels, width: int) -> bool:
+    return len(in_channels) in (1, 2) and all(c == 2 for c in in_channels) and width in (64, 128)
+
+
+class _Embed2(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, f, eps, *params):
+        branches = len(params) // 4
+        _need_gpu(f, *params)
+        lead = f.shape[:-1]
+        f2 = _rows2(f)
+        if f2.stride(0) % 2 != 0 or f2.data_ptr() % 8 != 0:
+            f2 = f2.contiguous()
+        m = f2.shape[0]
+        ps = [p.contiguous() for p in params]
+        ws, bs, gs, betas = ps[0::4], ps[1::4], ps[2::4], ps[3::4]
+        d = ws[0].shape[0]
+        h = torch.empty(m, branches * d, dtype=torch.float32, device=f.device)
+        _lib.call("hivt_embed2_fwd", _p(f2), f2.stride(0), branches, _ptr_array(ws), _ptr_array(bs), _ptr_array(gs),
+                  _ptr_array(betas), float(eps), m, d, _p(h), _stream(f))
+        ctx.save_for_backward(f2, *ps)
+        ctx.cfg = (branches, d, float(eps), tuple(lead), tuple(f.shape))
+        return h.view(*lead, branches * d)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        f2, *ps = ctx.saved_tensors
+        branches, d, eps, lead, f_shape = ctx.cfg
+        ws, bs, gs, betas = ps[0::4], ps[1::4], ps[2::4], ps[3::4]
+        m = f2.shape[0]
+        dev = f2.device
+        dh2 = _rows2(dh)
+        if dh2.stride(0) != branches * d or dh2.data_ptr() % 16 != 0:
+            dh2 = dh2.contiguous()
+        dparams = torch.empty(branches, 5 * d, dtype=torch.float32, device=dev)
+        df = torch.empty(m, 2 * branches, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws_buf = _workspace(_lib.query("hivt_embed2_bwd_workspace_bytes", m, d, branches), dev)
+        _lib.call("hivt_embed2_bwd", _p(dh2), _p(f2), f2.stride(0), branches, _ptr_array(ws), _ptr_array(bs),
+                  _ptr_array(gs), _ptr_array(betas), eps, m, d, _p(dparams), _p(df), _p(ws_buf), ws_buf.numel(),
+                  _stream(f2))
+        grads = []
+        for b in range(branches):
+            row = dparams[b]
+            grads += [row[:2 * d].view(d, 2), row[2 * d:3 * d], row[3 * d:4 * d], row[4 * d:5 * d]]
+        if df is not None:
+            if f_shape[-1] != 2 * branches:  # the input row was wider than the columns the branches read
+                full = torch.zeros(m, f_shape[-1], dtype=torch.float32, device=dev)
+                full[:, :2 * branches] = df
+                df = full
+            df = df.view(f_shape)
+        return (df, None, *grads)
+
+
+def embed2(f: torch.Tensor, branch_params, eps: float) -> torch.Tensor:
+    """``[ReLU(LN_b(f[..., 2b:2b+2] @ W_b.T + bias_b)) for b in branches]`` side by side, one launch.
+    ``branch_params`` is a list (1 or 2 entries) of ``(weight [D,2], bias, ln_weight, ln_bias)``."""
+    flat = [t for group in branch_params for t in group]
+    if f.shape[-1] < 2 * len(branch_params):
+        raise ValueError("input rows are narrower than two components per branch")
+    return _Embed2.apply(f, eps, *flat)

@@ -296,6 +296,30 @@ int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const
                              float* d_y_hat, float* d_pi, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * First stage of the embedding MLPs (two-component inputs)
+ * ------------------------------------------------------------------------------------------ */
+
+/* h[m, b*D : (b+1)*D] = ReLU(LayerNorm_b(W_b f[m, 2b:2b+2] + bias_b)) for `branches` (1 or 2) inputs of two
+ * components each, D in {64, 128}.  Replaces the Linear(2, D) + LayerNorm + ReLU that opens
+ * SingleInputEmbedding and every branch of MultipleInputEmbedding, and the concatenation of the branch
+ * outputs (models/embedding.py:12-19,36-44,49-52).  w / bias / gamma / beta are HOST arrays of `branches`
+ * device pointers (w[b] float [D,2] row-major, the others float [D], all 16-byte aligned); f rows are
+ * f_ld floats apart (even, 8-byte aligned); h is float [M, branches*D] contiguous. */
+int hivt_embed2_fwd(const float* f, int64_t f_ld, int32_t branches, const float* const* w, const float* const* bias,
+                    const float* const* gamma, const float* const* beta, float eps, int64_t M, int32_t D, float* h,
+                    hivt_stream_t stream);
+
+size_t hivt_embed2_bwd_workspace_bytes(int64_t M, int32_t D, int32_t branches);
+
+/* Gradients of the above from dh float [M, branches*D]; the pre-norm values are recomputed from f.
+ * dparams float [branches][5*D] receives, per branch: dW (D x 2, row-major) | dbias | dgamma | dbeta.
+ * df (optional, float [M, 2*branches]) receives the input gradient. */
+int hivt_embed2_bwd(const float* dh, const float* f, int64_t f_ld, int32_t branches, const float* const* w,
+                    const float* const* bias, const float* const* gamma, const float* const* beta, float eps,
+                    int64_t M, int32_t D, float* dparams, float* df, void* workspace, size_t workspace_bytes,
+                    hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Spectral normalisation of the critics' linear layers
  * ------------------------------------------------------------------------------------------ */
 

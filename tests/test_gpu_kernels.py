@@ -556,3 +556,36 @@ def test_layer_norm_kernel_vs_framework(shape):
         wide = torch.randn(shape[0], 2 * shape[1], generator=gen).to(DEV)
         view = wide[:, :shape[1]]
         close(ops.layer_norm(view, norm), norm(view), 1e-5)
+
+
+@pytest.mark.parametrize("M,D,B", [(1, 128, 2), (7, 64, 1), (1000, 128, 1), (68_617, 128, 2), (4099, 64, 2)])
+def test_embed_first_stage_kernel(M, D, B):
+    """ReLU(LN(Linear(2, D))) of one or two branches in one launch against the framework's layers,
+    forward and every gradient (the kernel recomputes the pre-norm values in backward)."""
+    gen = torch.Generator().manual_seed(M + D + B)
+    f = (torch.randn(M, 2 * B, generator=gen) * 4).to(DEV).requires_grad_(True)
+    lins = [torch.nn.Linear(2, D).to(DEV) for _ in range(B)]
+    norms = [torch.nn.LayerNorm(D).to(DEV) for _ in range(B)]
+    with torch.no_grad():
+        for n_ in norms:
+            n_.weight.copy_(torch.randn(D, generator=gen))
+            n_.bias.copy_(torch.randn(D, generator=gen) * 0.3)
+    go = torch.randn(M, B * D, generator=gen).to(DEV)
+    params = [(l.weight, l.bias, n_.weight, n_.bias) for l, n_ in zip(lins, norms)]
+    flat = [t for g in params for t in g]
+    h = ops.embed2(f, params, norms[0].eps)
+    got = torch.autograd.grad(h, [f] + flat, go)
+
+    f64 = f.detach().double().requires_grad_(True)
+    flat64 = [t.detach().double().requires_grad_(True) for t in flat]
+    outs = []
+    for b in range(B):
+        w, bias, g, be = flat64[4 * b:4 * b + 4]
+        z = f64[:, 2 * b:2 * b + 2] @ w.t() + bias
+        outs.append(torch.relu(torch.nn.functional.layer_norm(z, (D,), g, be, norms[0].eps)))
+    ref = torch.cat(outs, dim=-1)
+    want = torch.autograd.grad(ref, [f64] + flat64, go.double())
+    close(h, ref.float(), 1e-5)
+    for a, b_ in zip(got, want):
+        # ReLU kinks: an element within rounding of zero may flip; bound the comparison by the tensor scale
+        close(a, b_.float(), 1e-4, atol=2e-5)
