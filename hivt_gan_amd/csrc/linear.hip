@@ -206,7 +206,8 @@ struct Core {
   template <bool RELU>
   __device__ static void store_direct(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
                                       float* __restrict__ out, int64_t out_ld, const float* __restrict__ bias,
-                                      const float* __restrict__ add, int64_t add_ld) {
+                                      const float* __restrict__ add, int64_t add_ld,
+                                      const int32_t* __restrict__ add_index, int32_t add_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int lo = lane & 31, hi = lane >> 5;
@@ -220,8 +221,9 @@ struct Core {
       if (gr < rows) {
         float v0 = acc0[r] + b0, v1 = acc1[r] + b1;
         if (add != nullptr) {
-          if (ok0) v0 += add[(int64_t)gr * add_ld + c0];
-          if (ok1) v1 += add[(int64_t)gr * add_ld + c1];
+          const int64_t ar = add_index != nullptr ? min(max(add_index[gr], 0), add_rows - 1) : gr;
+          if (ok0) v0 += add[ar * add_ld + c0];
+          if (ok1) v1 += add[ar * add_ld + c1];
         }
         if (RELU) {
           v0 = fmaxf(v0, 0.0f);
@@ -242,6 +244,8 @@ struct FwdArgs {
   const float* bias;
   const float* add;
   int64_t add_ld;
+  const int32_t* add_index;  // optional: row gr adds add[add_index[gr]] (rows of a small table)
+  int32_t add_rows;          // rows of that table; indices are clamped into it
   const float* gamma;
   const float* beta;
   float eps;
@@ -262,7 +266,8 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   f32x16 acc0, acc1;
   C::accumulate(xa, wa, row0, col0, 0, a.x.red, lds, acc0, acc1);
   if (EPI == EPI_NONE || EPI == EPI_RELU) {
-    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.bias, a.add, a.add_ld);
+    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.bias, a.add, a.add_ld,
+                                              a.add_index, a.add_rows);
     return;
   }
   // LayerNorm over the full output row: the row is spread over the waves, so it goes through LDS;
@@ -290,12 +295,15 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
       const int rr = r + 4 * u, gr = row0 + rr;
       okr[u] = rr < BM && gr < a.M;
       sum[u] = 0.0f;
+      const int64_t ar = (okr[u] && a.add != nullptr && a.add_index != nullptr)
+                             ? min(max(a.add_index[gr], 0), a.add_rows - 1)
+                             : gr;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         float v = 0.0f;
         if (okr[u] && okc[j]) {
           v = lds[rr * C::C_PITCH + lane + 64 * j] + bias[j];
-          if (a.add) v += a.add[(int64_t)gr * a.add_ld + col0 + lane + 64 * j];
+          if (a.add) v += a.add[ar * a.add_ld + col0 + lane + 64 * j];
         }
         vals[u][j] = v;
         sum[u] += v;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
-  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, nullptr, nullptr, 0);
+  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, nullptr, nullptr, 0, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,6 +632,55 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// out[code][c] = sum over rows m with index[m] == code of x[m][c], for a handful of codes (<= 16):
+// the gradient of a small embedding table whose rows were added per row of a big tensor.  A wave
+// strides over rows with one register accumulator per (code, owned column); selection by comparison
+// instead of indexed accumulation keeps everything in registers and the sums in a fixed order.
+constexpr int kMaxCodes = 16;
+
+template <int NPL>
+__global__ __launch_bounds__(256) void rowsum_by_code_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                             const int32_t* __restrict__ index, int64_t M, int N,
+                                                             int R, float* __restrict__ partial /*[grid][R][N]*/) {
+  __shared__ float red[4][kMaxCodes][64 * NPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * NPL;
+  float acc[kMaxCodes][NPL];
+#pragma unroll
+  for (int r = 0; r < kMaxCodes; ++r)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) acc[r][j] = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t m0 = (int64_t)blockIdx.x * 4 + wave; m0 < M; m0 += 2 * stride) {
+    float v[2][NPL];
+    int code[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t m = m0 + u * stride;
+      const bool ok = m < M;
+      const int64_t mc = ok ? m : m0;
+      code[u] = ok ? index[mc] : -1;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) v[u][j] = c0 + j < N ? x[mc * x_ld + c0 + j] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < kMaxCodes; ++r)
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) acc[r][j] += (code[u] == r) ? v[u][j] : 0.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < kMaxCodes; ++r)
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) red[wave][r][c0 + j] = acc[r][j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * N; i += 256) {
+    const int r = i / N, c = i % N;
+    partial[((int64_t)blockIdx.x * R + r) * N + c] = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans) {
@@ -660,7 +717,8 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
 using namespace hivt;
 
 extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
-                               const float* add, int64_t add_ld, const float* gamma, const float* beta, float eps,
+                               const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
+                               const float* gamma, const float* beta, float eps,
                                int epilogue, int64_t M, int32_t N, int32_t K, float* y, int64_t y_ld, float* z,
                                int64_t z_ld, float* stats, hivt_stream_t stream) {
   const char* what = "hivt_linear_fwd";
@@ -669,13 +727,15 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
                epilogue);
   if (M == 0) return HIVT_OK;
   HIVT_REQUIRE(x && w && y, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(add_index == nullptr || (add != nullptr && add_rows >= 1), HIVT_ERR_ARG,
+               "%s: add_index needs a table in add with add_rows >= 1", what);
   const bool ln = epilogue == EPI_LN || epilogue == EPI_LN_RELU;
   HIVT_REQUIRE(!ln || (gamma && beta && N <= 128), HIVT_ERR_ARG,
                "%s: LayerNorm epilogue needs gamma, beta and N <= 128 (N=%d)", what, N);
   FwdArgs a{};
   a.x = make_operand(x, x_ld, (int32_t)M, K, true);
   a.w = make_operand(w, w_ld, N, K, true);
-  a.bias = bias; a.add = add; a.add_ld = add_ld; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.bias = bias; a.add = add; a.add_ld = add_ld; a.add_index = add_index; a.add_rows = add_rows; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
@@ -846,6 +906,44 @@ extern "C" int hivt_ln_fwd(const float* x, int64_t x_ld, const float* gamma, con
   else
     hipLaunchKernelGGL((ln_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, gamma, beta, eps, M, N, vec,
                        y, y_ld, stats);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" size_t hivt_rowsum_by_code_workspace_bytes(int64_t M, int32_t N, int32_t R) {
+  int64_t blocks = (M + 7) / 8;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return align_up((size_t)blocks * (size_t)R * (size_t)N * sizeof(float), 256);
+}
+
+extern "C" int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* index, int64_t M, int32_t N,
+                                   int32_t R, float* out, void* workspace, size_t workspace_bytes,
+                                   hivt_stream_t stream) {
+  const char* what = "hivt_rowsum_by_code";
+  HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128 && R > 0 && R <= kMaxCodes, HIVT_ERR_ARG,
+               "%s: need N in [1,128] and at most %d codes (N=%d, R=%d)", what, kMaxCodes, N, R);
+  HIVT_REQUIRE(out != nullptr, HIVT_ERR_ARG, "%s: out is null", what);
+  hipStream_t s = (hipStream_t)stream;
+  if (M == 0) {
+    zero_words(out, (int64_t)R * N, s);
+    HIVT_CHECK_LAUNCH(what);
+    return HIVT_OK;
+  }
+  HIVT_REQUIRE(x && index, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace && workspace_bytes >= hivt_rowsum_by_code_workspace_bytes(M, N, R), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small", what);
+  int64_t blocks = (M + 7) / 8;
+  if (blocks > 512) blocks = 512;
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (N <= 64)
+    hipLaunchKernelGGL((rowsum_by_code_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+                       partial);
+  else
+    hipLaunchKernelGGL((rowsum_by_code_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+                       partial);
+  HIVT_CHECK_LAUNCH(what);
+  reduce_partials(partial, (int)blocks, R * N, out, s);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

@@ -1,5 +1,6 @@
-"""Multi-modal trajectory decoder (dense; stock GEMMs).  Parameter names follow
-``models/decoder.py:74-139`` (``aggr_embed.{0,1}``, ``loc.{0,1,3}``, ``scale.{0,1,3}``, ``pi.{0,1,3,4,6}``)."""
+"""Multi-modal trajectory decoder.  Parameter names follow ``models/decoder.py:74-139``
+(``aggr_embed.{0,1}``, ``loc.{0,1,3}``, ``scale.{0,1,3}``, ``pi.{0,1,3,4,6}``).  On the GPU every
+Linear (+LayerNorm +ReLU) group is one fused launch; CPU tensors run the stock layers."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -8,7 +9,24 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .embedding import init_weights
+
+
+def _run(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """``seq(x)`` for a stack of Linear [, LayerNorm [, ReLU]] groups, one fused launch per group on the GPU."""
+    if not x.is_cuda:
+        return seq(x)
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        norm = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LayerNorm) else None
+        j = i + (2 if norm is not None else 1)
+        relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+        x = ops.fused_linear(x, lin.weight, lin.bias, layer_norm=norm, relu=relu)
+        i = j + (1 if relu else 0)
+    return x
 
 
 def _head(width: int, out: int) -> nn.Sequential:
@@ -38,11 +56,11 @@ class MLPDecoder(nn.Module):
     def forward(self, local_embed: torch.Tensor, global_embed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """local_embed [N, D], global_embed [F, N, D] -> (y_hat [F, N, H, 4 or 2], pi [N, F])."""
         tiled = local_embed.expand(self.num_modes, *local_embed.shape)
-        pi = self.pi(torch.cat((tiled, global_embed), dim=-1)).squeeze(-1).t()
-        out = self.aggr_embed(torch.cat((global_embed, tiled), dim=-1))
-        loc = self.loc(out).view(self.num_modes, -1, self.future_steps, 2)
+        pi = _run(self.pi, torch.cat((tiled, global_embed), dim=-1)).squeeze(-1).t()
+        out = _run(self.aggr_embed, torch.cat((global_embed, tiled), dim=-1))
+        loc = _run(self.loc, out).view(self.num_modes, -1, self.future_steps, 2)
         if not self.uncertain:
             return loc, pi
-        scale = F.elu(self.scale(out), alpha=1.0) + 1.0
+        scale = F.elu(_run(self.scale, out), alpha=1.0) + 1.0
         scale = torch.clamp(scale.view(self.num_modes, -1, self.future_steps, 2), min=0.05)
         return torch.cat((loc, scale), dim=-1), pi

@@ -87,7 +87,7 @@ class MultipleInputEmbedding(nn.Module):
         self.apply(init_weights)
 
     def _fuse(self, branch_inputs: Sequence[torch.Tensor], extra: Optional[torch.Tensor],
-              packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+              packed: Optional[torch.Tensor] = None, extra_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Branch first layers (Linear+LN+ReLU; one streaming launch for all branches when every input
         has two components, else one launch each), then ALL second linears as one product over the
         concatenated hidden rows ([h_0 | h_1 | ..] @ [W_0 | W_1 | ..]^T + sum of biases, which equals
@@ -109,7 +109,7 @@ class MultipleInputEmbedding(nn.Module):
         for br in self.module_list[1:]:
             bias = bias + br[3].bias
         a = self.aggr_embed
-        h = ops.fused_linear(h, weight, bias, add=extra, layer_norm=a[0], relu=True)
+        h = ops.fused_linear(h, weight, bias, add=extra, layer_norm=a[0], relu=True, add_index=extra_index)
         return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
 
     def forward(self, continuous_inputs: List[torch.Tensor],
@@ -121,11 +121,14 @@ class MultipleInputEmbedding(nn.Module):
                 cat = cat + extra
         return self._fuse(continuous_inputs, cat)
 
-    def forward_packed(self, packed: torch.Tensor, categorical_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_packed(self, packed: torch.Tensor, categorical_sum: Optional[torch.Tensor] = None,
+                       categorical_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same computation for inputs packed side by side in one [E, sum(in_channels)] record
-        (the layout the gather kernel emits)."""
+        (the layout the gather kernel emits).  With ``categorical_index`` (int32 per row),
+        ``categorical_sum`` is a small table of already summed categorical embeddings and row e adds
+        ``categorical_sum[categorical_index[e]]``."""
         parts, col = [], 0
         for width in self.in_channels:
             parts.append(packed[:, col:col + width])
             col += width
-        return self._fuse(parts, categorical_sum, packed if col == packed.shape[-1] else None)
+        return self._fuse(parts, categorical_sum, packed if col == packed.shape[-1] else None, categorical_index)

@@ -108,7 +108,9 @@ class HiVT(nn.Module):
             sin, cos = torch.sin(ang), torch.cos(ang)
             rotate_mat = torch.stack([cos, -sin, sin, cos], dim=-1).view(-1, 2, 2)
             if data.get("y") is not None:
-                data["y"] = torch.bmm(data["y"], rotate_mat)
+                # [N, H, 2] x [N, 2, 2] written out: a batch of N 2x2 products is not worth a GEMM launch
+                y = data["y"]
+                data["y"] = y[..., 0:1] * rotate_mat[:, None, 0, :] + y[..., 1:2] * rotate_mat[:, None, 1, :]
             data["rotate_mat"] = rotate_mat
         else:
             data["rotate_mat"] = None

@@ -176,13 +176,13 @@ class AAEncoder(_EdgeAttentionBase):
         if batched:
             n = x.shape[0] // T
             xv = x.view(T, n, -1)
-            if rotate_mat is not None:
-                xv = torch.matmul(xv.unsqueeze(-2), rotate_mat.expand(T, *rotate_mat.shape)).squeeze(-2)
+            if rotate_mat is not None:  # row vector times the agent's 2x2, written out (no batched GEMM)
+                xv = xv[..., 0:1] * rotate_mat[:, 0, :] + xv[..., 1:2] * rotate_mat[:, 1, :]
             center = self.center_embed(xv)
             center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2), center).reshape(x.shape[0], -1)
             rot_mod = n
         else:
-            xr = x if rotate_mat is None else torch.bmm(x.unsqueeze(-2), rotate_mat).squeeze(-2)
+            xr = x if rotate_mat is None else x[:, 0:1] * rotate_mat[:, 0, :] + x[:, 1:2] * rotate_mat[:, 1, :]
             center = self.center_embed(xr)
             center = torch.where(bos_mask.unsqueeze(-1), self.bos_token[t], center)
             rot_mod = x.shape[0]
@@ -232,11 +232,10 @@ class ALEncoder(_EdgeAttentionBase):
                                                      edges.perm, x_actor.shape[0], edges.count)
         table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
                  + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
-        # rows of the 12-entry table picked per edge as a one-hot GEMM: its backward is a dense
-        # [12, E] x [E, D] product instead of E*D contended atomic adds into 12 rows
-        one_hot = F.one_hot(lane_code.index_select(0, src_csr.long()), 12).to(table.dtype)
-        cat_sum = one_hot @ table
-        return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, cat_sum), edges)
+        # the 12-row table is added per edge inside the embedding's second launch (row picked by the
+        # lane's code); its gradient is a per-code sum of rows, not E*D contended atomic adds
+        code_per_edge = lane_code.to(torch.int32).index_select(0, src_csr)
+        return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, table, code_per_edge), edges)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -469,7 +469,7 @@ def linear_fused_supported(n_out: int, layer_norm: bool) -> bool:
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps):
+    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index):
         _need_gpu(x, weight)
         lead = x.shape[:-1]
         x2 = _rows2(x)
@@ -480,6 +480,10 @@ class _FusedLinear(torch.autograd.Function):
         w2 = _rows2(weight)
         ln = gamma is not None
         add2 = _rows2(add) if add is not None else None
+        if add_index is not None:
+            if add is None or add_index.dtype != torch.int32 or add_index.shape != (m,):
+                raise ValueError("add_index must be an int32 vector with one entry per row, next to a table in `add`")
+            add_index = add_index.contiguous()
         y = torch.empty(m, n, dtype=torch.float32, device=x.device)
         z = torch.empty(m, n, dtype=torch.float32, device=x.device) if ln else None
         stats = torch.empty(m, 2, dtype=torch.float32, device=x.device) if ln else None
@@ -488,9 +492,10 @@ class _FusedLinear(torch.autograd.Function):
         beta_c = beta.contiguous() if ln else None
         bias_c = bias.contiguous() if bias is not None else None
         _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias_c), _p(add2),
-                  add2.stride(0) if add2 is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi, m, n, k, _p(y),
-                  n, _p(z), n, _p(stats), _stream(x))
-        ctx.save_for_backward(x2, w2, z, stats, gamma_c, beta_c, y if (relu and not ln) else None)
+                  add2.stride(0) if add2 is not None else 0, _p(add_index),
+                  add2.shape[0] if add_index is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi,
+                  m, n, k, _p(y), n, _p(z), n, _p(stats), _stream(x))
+        ctx.save_for_backward(x2, w2, z, stats, gamma_c, beta_c, y if (relu and not ln) else None, add_index)
         ctx.cfg = (bool(relu), ln, tuple(lead), bias is not None, add is not None,
                    tuple(add.shape) if add is not None else None)
         return y.view(*lead, n)
@@ -498,7 +503,7 @@ class _FusedLinear(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, w2, z, stats, gamma, beta, y_relu = ctx.saved_tensors
+        x2, w2, z, stats, gamma, beta, y_relu, add_index = ctx.saved_tensors
         relu, ln, lead, has_bias, has_add, add_shape = ctx.cfg
         m, k = x2.shape
         n = w2.shape[0]
@@ -528,8 +533,17 @@ class _FusedLinear(torch.autograd.Function):
             ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
             _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(x2), x2.stride(0), m, n, k, _p(dw), _p(db),
                       _p(ws), ws.numel(), s)
-        dadd = dz.view(add_shape) if (has_add and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dadd, dgamma, dbeta, None, None
+        dadd = None
+        if has_add and ctx.needs_input_grad[3]:
+            if add_index is None:
+                dadd = dz.view(add_shape)
+            else:  # gradient of the table: per-code sums of the rows of dz
+                codes = add_shape[0]
+                dadd = torch.empty(codes, n, dtype=torch.float32, device=dev)
+                ws = _workspace(_lib.query("hivt_rowsum_by_code_workspace_bytes", m, n, codes), dev)
+                _lib.call("hivt_rowsum_by_code", _p(dz), dz.stride(0), _p(add_index), m, n, codes, _p(dadd), _p(ws),
+                          ws.numel(), s)
+        return dx, dw, db, dadd, dgamma, dbeta, None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -575,8 +589,10 @@ def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
 
 def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  add: Optional[torch.Tensor] = None, layer_norm: Optional[torch.nn.LayerNorm] = None,
-                 relu: bool = False) -> torch.Tensor:
+                 relu: bool = False, add_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[relu]([layer_norm](x @ weight.T + bias [+ add]))`` in one launch (exact fp32 on the matrix cores).
+    With ``add_index`` (int32, one entry per row) ``add`` is a small table [codes <= 16, N] and row m adds
+    ``add[add_index[m]]``.
 
     Falls back to the stock GPU ops only where no kernel exists for the shape (LayerNorm wider than
     128 columns); CPU tensors are refused."""
@@ -585,14 +601,14 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if not linear_fused_supported(n, layer_norm is not None):
         y = torch.nn.functional.linear(x, weight, bias)
         if add is not None:
-            y = y + add
+            y = y + (add if add_index is None else add.index_select(0, add_index.long()))
         if layer_norm is not None:
             y = layer_norm(y)
         return torch.relu(y) if relu else y
     gamma = layer_norm.weight if layer_norm is not None else None
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0
-    return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps)
+    return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps, add_index)
 
 
 # --------------------------------------------------------------------------------------------

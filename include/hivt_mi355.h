@@ -204,7 +204,9 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
 #define HIVT_EPI_LN_RELU 3
 
 /* y = epilogue(x w^T + bias [+ add]) for x float [M,K] (row stride x_ld), w float [N,K] (nn.Linear
- * layout, row stride w_ld), bias [N] or NULL, add [M,N] or NULL.  Epilogues: none, ReLU,
+ * layout, row stride w_ld), bias [N] or NULL, add [M,N] or NULL; with add_index (int32 [M], optional)
+ * row m adds add[clamp(add_index[m], 0, add_rows-1)] instead -- the rows of a small embedding table, which is how the summed
+ * categorical lane embeddings enter (models/local_encoder.py:349-357).  Epilogues: none, ReLU,
  * LayerNorm(gamma, beta, eps) and LayerNorm + ReLU (N <= 128); the LayerNorm epilogues also write
  * the pre-normalisation values z (optional) and per-row (mean, rstd) into stats [M,2].
  * Replaces nn.Linear / nn.LayerNorm / nn.ReLU chains of the per-edge embedding MLPs
@@ -212,9 +214,9 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
  * (models/local_encoder.py:106-113, models/global_interactor.py:79-88) and the feed-forward blocks
  * (models/local_encoder.py:117-122). */
 int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
-                    const float* add, int64_t add_ld, const float* gamma, const float* beta, float eps,
-                    int epilogue, int64_t M, int32_t N, int32_t K, float* y, int64_t y_ld, float* z,
-                    int64_t z_ld, float* stats, hivt_stream_t stream);
+                    const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
+                    const float* gamma, const float* beta, float eps, int epilogue, int64_t M, int32_t N, int32_t K, float* y,
+                    int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream);
 
 /* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue). */
 int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
@@ -294,6 +296,15 @@ int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const
                              const uint8_t* padding_mask, int64_t pm_stride, int32_t t_hist, int32_t F,
                              int32_t N, int32_t Hf, const int64_t* best, const float* soft, const float* stats,
                              float* d_y_hat, float* d_pi, hivt_stream_t stream);
+
+size_t hivt_rowsum_by_code_workspace_bytes(int64_t M, int32_t N, int32_t R);
+
+/* out[r][c] = sum over rows m with index[m] == r of x[m][c], for R <= 16 codes and N <= 128 columns,
+ * summed in a fixed order.  It is the gradient of the table handed to hivt_linear_fwd through
+ * add / add_index (x = gradient at the pre-normalisation sum), replacing the scatter of per-edge
+ * gradients into the categorical embedding parameters. */
+int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* index, int64_t M, int32_t N, int32_t R,
+                        float* out, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * First stage of the embedding MLPs (two-component inputs)

@@ -589,3 +589,31 @@ def test_embed_first_stage_kernel(M, D, B):
     for a, b_ in zip(got, want):
         # ReLU kinks: an element within rounding of zero may flip; bound the comparison by the tensor scale
         close(a, b_.float(), 1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,N,codes", [(5000, 256, 128, 12), (333, 64, 64, 3), (1, 128, 128, 16)])
+def test_fused_linear_with_table_rows_added(M, K, N, codes):
+    """A small table whose rows are added per input row (categorical embeddings) inside the LayerNorm
+    epilogue; its gradient is the per-code sum of the pre-norm gradient rows."""
+    gen = torch.Generator().manual_seed(M + K + codes)
+    x = torch.randn(M, K, generator=gen).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    norm = torch.nn.LayerNorm(N).to(DEV)
+    table = torch.randn(codes, N, generator=gen).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, codes, (M,), generator=gen).to(torch.int32).to(DEV)
+    go = torch.randn(M, N, generator=gen).to(DEV)
+    y = ops.fused_linear(x, lin.weight, lin.bias, add=table, layer_norm=norm, relu=True, add_index=idx)
+    got = torch.autograd.grad(y, (x, lin.weight, lin.bias, table, norm.weight, norm.bias), go)
+    ref = torch.relu(norm(lin(x) + table.index_select(0, idx.long())))
+    want = torch.autograd.grad(ref, (x, lin.weight, lin.bias, table, norm.weight, norm.bias), go)
+    close(y, ref, 1e-5, atol=1e-5)
+    for a, b in zip(got, want):
+        close(a, b, 1e-4, atol=2e-5)
+    # indices outside the table are clamped on the way in and ignored on the way back
+    bad = idx.clone()
+    bad[0] = 1000
+    y2 = ops.fused_linear(x, lin.weight, lin.bias, add=table, layer_norm=norm, relu=True, add_index=bad)
+    fixed = idx.clone()
+    fixed[0] = codes - 1
+    ref2 = torch.relu(norm(lin(x) + table.index_select(0, fixed.long())))
+    close(y2, ref2, 1e-5, atol=1e-5)
