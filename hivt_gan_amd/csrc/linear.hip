@@ -119,6 +119,21 @@ struct Stage {
   }
 };
 
+// What the direct epilogue applies to an accumulator element before it is stored:
+//   out = residual + dropout([relu](acc + bias[col] + add[row or add_index[row]][col]))
+struct Tail {
+  const float* bias = nullptr;
+  const float* add = nullptr;
+  int64_t add_ld = 0;
+  const int32_t* add_index = nullptr;  // optional: row gr adds add[add_index[gr]] (rows of a small table)
+  int32_t add_rows = 0;                // rows of that table; indices are clamped into it
+  float drop_p = 0.0f;                 // dropout probability; the mask is uniform01(seed, row * cols + col) >= p
+  uint64_t seed = 0;
+  const uint64_t* seed_ptr = nullptr;  // optional device-side value added to seed
+  const float* residual = nullptr;
+  int64_t res_ld = 0;
+};
+
 template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false>
 struct Core {
   using SA = Stage<BM, TA, VEC, ACC_A>;
@@ -202,32 +217,41 @@ struct Core {
 
   // accumulators -> global memory without the LDS round trip: for a fixed register the 32 low lanes
   // hold 32 consecutive columns of one row (a 128-byte segment) and the high lanes the row 4 below.
-  // out = [relu](acc + bias[col] + add[row][col]); bias / add may be null.
   template <bool RELU>
   __device__ static void store_direct(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
-                                      float* __restrict__ out, int64_t out_ld, const float* __restrict__ bias,
-                                      const float* __restrict__ add, int64_t add_ld,
-                                      const int32_t* __restrict__ add_index, int32_t add_rows) {
+                                      float* __restrict__ out, int64_t out_ld, const Tail& t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int lo = lane & 31, hi = lane >> 5;
     const int c0 = col0 + wc * 64 + lo, c1 = c0 + 32;
     const bool ok0 = c0 < cols, ok1 = c1 < cols;
-    const float b0 = (bias != nullptr && ok0) ? bias[c0] : 0.0f;
-    const float b1 = (bias != nullptr && ok1) ? bias[c1] : 0.0f;
+    const float b0 = (t.bias != nullptr && ok0) ? t.bias[c0] : 0.0f;
+    const float b1 = (t.bias != nullptr && ok1) ? t.bias[c1] : 0.0f;
+    const bool drop = t.drop_p > 0.0f;
+    const float keep_scale = drop ? 1.0f / (1.0f - t.drop_p) : 1.0f;
+    const uint64_t seed = t.seed + ((drop && t.seed_ptr != nullptr) ? *t.seed_ptr : 0ull);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gr = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (gr < rows) {
         float v0 = acc0[r] + b0, v1 = acc1[r] + b1;
-        if (add != nullptr) {
-          const int64_t ar = add_index != nullptr ? min(max(add_index[gr], 0), add_rows - 1) : gr;
-          if (ok0) v0 += add[ar * add_ld + c0];
-          if (ok1) v1 += add[ar * add_ld + c1];
+        if (t.add != nullptr) {
+          const int64_t ar = t.add_index != nullptr ? min(max(t.add_index[gr], 0), t.add_rows - 1) : gr;
+          if (ok0) v0 += t.add[ar * t.add_ld + c0];
+          if (ok1) v1 += t.add[ar * t.add_ld + c1];
         }
         if (RELU) {
           v0 = fmaxf(v0, 0.0f);
           v1 = fmaxf(v1, 0.0f);
+        }
+        if (drop) {
+          const uint64_t base = (uint64_t)gr * (uint64_t)cols;
+          v0 = uniform01(seed, base + (uint64_t)c0) >= t.drop_p ? v0 * keep_scale : 0.0f;
+          v1 = uniform01(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
+        }
+        if (t.residual != nullptr) {
+          if (ok0) v0 += t.residual[(int64_t)gr * t.res_ld + c0];
+          if (ok1) v1 += t.residual[(int64_t)gr * t.res_ld + c1];
         }
         if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
         if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
@@ -241,11 +265,7 @@ struct Core {
 // ---------------------------------------------------------------------------------------------
 struct FwdArgs {
   Operand x, w;
-  const float* bias;
-  const float* add;
-  int64_t add_ld;
-  const int32_t* add_index;  // optional: row gr adds add[add_index[gr]] (rows of a small table)
-  int32_t add_rows;          // rows of that table; indices are clamped into it
+  Tail t;
   const float* gamma;
   const float* beta;
   float eps;
@@ -266,8 +286,7 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   f32x16 acc0, acc1;
   C::accumulate(xa, wa, row0, col0, 0, a.x.red, lds, acc0, acc1);
   if (EPI == EPI_NONE || EPI == EPI_RELU) {
-    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.bias, a.add, a.add_ld,
-                                              a.add_index, a.add_rows);
+    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.t);
     return;
   }
   // LayerNorm over the full output row: the row is spread over the waves, so it goes through LDS;
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   for (int j = 0; j < CPL; ++j) {
     const int gc = col0 + lane + 64 * j;
     okc[j] = gc < a.N;
-    bias[j] = (okc[j] && a.bias != nullptr) ? a.bias[gc] : 0.0f;
+    bias[j] = (okc[j] && a.t.bias != nullptr) ? a.t.bias[gc] : 0.0f;
     gam[j] = okc[j] ? a.gamma[gc] : 0.0f;
     bet[j] = okc[j] ? a.beta[gc] : 0.0f;
   }
@@ -295,15 +314,15 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
       const int rr = r + 4 * u, gr = row0 + rr;
       okr[u] = rr < BM && gr < a.M;
       sum[u] = 0.0f;
-      const int64_t ar = (okr[u] && a.add != nullptr && a.add_index != nullptr)
-                             ? min(max(a.add_index[gr], 0), a.add_rows - 1)
+      const int64_t ar = (okr[u] && a.t.add != nullptr && a.t.add_index != nullptr)
+                             ? min(max(a.t.add_index[gr], 0), a.t.add_rows - 1)
                              : gr;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
         float v = 0.0f;
         if (okr[u] && okc[j]) {
           v = lds[rr * C::C_PITCH + lane + 64 * j] + bias[j];
-          if (a.add) v += a.add[ar * a.add_ld + col0 + lane + 64 * j];
+          if (a.t.add) v += a.t.add[ar * a.t.add_ld + col0 + lane + 64 * j];
         }
         vals[u][j] = v;
         sum[u] += v;
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
-  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, nullptr, nullptr, 0, nullptr, 0);
+  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, Tail{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,7 +390,8 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
 struct WgradArgs {
   Operand dy, x;   // both [red = m][row]: dy rows = n, x rows = k
   float* partial;  // [chunks][N][K]
-  float* bias_partial;  // [chunks][N] or null
+  float* bias_partial;  // start of chunk 0's bias sums (each chunk: N*K weight sums, then N bias sums) or null
+  int64_t pitch;        // floats per chunk: N*K (+ N with a bias)
   int32_t N, K, M, chunk_rows;
 };
 
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   f32x16 acc0, acc1;
   C::accumulate(dy, x, row0, col0, m_begin, m_end, lds, acc0, acc1, &colsum);
   C::spill(lds, acc0, acc1);
-  float* out = a.partial + (int64_t)chunk * a.N * a.K;
+  float* out = a.partial + (int64_t)chunk * a.pitch;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = wave; r < BM; r += 4) {
     const int gr = row0 + r;
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
       float t = 0.0f;
 #pragma unroll
       for (int i = 0; i < GROUPS; ++i) t += bsum[i][threadIdx.x];
-      a.bias_partial[(int64_t)chunk * a.N + row0 + threadIdx.x] = t;
+      a.bias_partial[(int64_t)chunk * a.pitch + row0 + threadIdx.x] = t;
     }
   }
 }
@@ -681,6 +701,30 @@ __global__ __launch_bounds__(256) void rowsum_by_code_kernel(const float* __rest
   }
 }
 
+// Gradient through the direct epilogue's dropout (and ReLU): dz = dy * keep * 1/(1-p) [* (y > 0)].
+// With a ReLU in front of the dropout, y > 0 already says "active and kept", so the mask is not
+// regenerated; without one it is recomputed from (seed, row * N + col) exactly as the forward did.
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, int64_t dy_ld,
+                                                          const float* __restrict__ y, int64_t y_ld, int relu,
+                                                          float p, uint64_t seed_host,
+                                                          const uint64_t* __restrict__ seed_ptr, int64_t M, int N,
+                                                          float* __restrict__ dz, int64_t dz_ld) {
+  const float scale = 1.0f / (1.0f - p);
+  const uint64_t seed = seed_host + (seed_ptr != nullptr ? *seed_ptr : 0ull);
+  const int64_t total = M * (int64_t)N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / N;
+    const int c = (int)(i - m * N);
+    const float g = dy[m * dy_ld + c];
+    bool keep;
+    if (relu)
+      keep = y[m * y_ld + c] > 0.0f;
+    else
+      keep = p <= 0.0f || uniform01(seed, (uint64_t)i) >= p;
+    dz[m * dz_ld + c] = keep ? g * scale : 0.0f;
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans) {
@@ -719,8 +763,9 @@ using namespace hivt;
 extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
                                const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
                                const float* gamma, const float* beta, float eps,
-                               int epilogue, int64_t M, int32_t N, int32_t K, float* y, int64_t y_ld, float* z,
-                               int64_t z_ld, float* stats, hivt_stream_t stream) {
+                               int epilogue, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
+                               const float* residual, int64_t res_ld, int64_t M, int32_t N, int32_t K, float* y,
+                               int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream) {
   const char* what = "hivt_linear_fwd";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LN_RELU, HIVT_ERR_ARG, "%s: unknown epilogue %d", what,
@@ -735,7 +780,12 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
   FwdArgs a{};
   a.x = make_operand(x, x_ld, (int32_t)M, K, true);
   a.w = make_operand(w, w_ld, N, K, true);
-  a.bias = bias; a.add = add; a.add_ld = add_ld; a.add_index = add_index; a.add_rows = add_rows; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  HIVT_REQUIRE(!ln || (dropout_p == 0.0f && residual == nullptr), HIVT_ERR_UNSUPPORTED,
+               "%s: dropout / residual are not built for the LayerNorm epilogues", what);
+  a.t.bias = bias; a.t.add = add; a.t.add_ld = add_ld; a.t.add_index = add_index; a.t.add_rows = add_rows;
+  a.t.drop_p = dropout_p; a.t.seed = seed; a.t.seed_ptr = seed_ptr; a.t.residual = residual; a.t.res_ld = res_ld;
+  a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
@@ -826,7 +876,8 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   a.dy = make_operand(dy, dy_ld, N, (int32_t)M, false);
   a.x = make_operand(x, x_ld, K, (int32_t)M, false);
   a.partial = reinterpret_cast<float*>(workspace);
-  a.bias_partial = dbias ? a.partial + (size_t)real_chunks * N * K : nullptr;
+  a.pitch = (int64_t)N * K + (dbias ? N : 0);
+  a.bias_partial = dbias ? a.partial + (size_t)N * K : nullptr;
   a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
   if (a.dy.vec_ok && a.x.vec_ok)
@@ -834,15 +885,11 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   else
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, false>), grid, dim3(kThreads), 0, s, a);
   HIVT_CHECK_LAUNCH(what);
-  const int cnt = N * K;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(256), 0, s, a.partial, real_chunks,
-                     (int64_t)cnt, cnt, dw);
+  // one reduction over the chunks for the weight sums and (columns beyond N*K) the bias sums
+  const int cnt = N * K, cols = (int)a.pitch;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, s, a.partial, real_chunks,
+                     a.pitch, cols, dw, cnt, dbias);
   HIVT_CHECK_LAUNCH(what);
-  if (dbias) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, a.bias_partial,
-                       real_chunks, (int64_t)N, N, dbias);
-    HIVT_CHECK_LAUNCH(what);
-  }
   return HIVT_OK;
 }
 
@@ -944,6 +991,22 @@ extern "C" int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* 
                        partial);
   HIVT_CHECK_LAUNCH(what);
   reduce_partials(partial, (int)blocks, R * N, out, s);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
+                                uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz,
+                                int64_t dz_ld, hivt_stream_t stream) {
+  const char* what = "hivt_dropout_bwd";
+  HIVT_REQUIRE(M >= 0 && N > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(dy && dz && (!relu || y), HIVT_ERR_ARG, "%s: null pointer", what);
+  int64_t blocks = (M * (int64_t)N + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld,
+                     relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

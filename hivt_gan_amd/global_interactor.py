@@ -50,11 +50,11 @@ class GlobalInteractorLayer(nn.Module):
             edges = _edge_set_from_coo(edge_index, edge_attr.new_zeros(edge_attr.shape[0], 2), x.shape[0], x.shape[0])
             edges.src = edges.coo_src.index_select(0, edges.perm.long())
             edge_attr = edge_attr.index_select(0, edges.perm.long())
-        x = x + self._mha_block(ops.layer_norm(x, self.norm1), edges, edge_attr)
-        x = x + self._ff_block(ops.layer_norm(x, self.norm2))
-        return x
+        x = self._mha_block(ops.layer_norm(x, self.norm1), edges, edge_attr, residual=x)
+        return self._ff_block(ops.layer_norm(x, self.norm2), residual=x)
 
-    def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor) -> torch.Tensor:
+    def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor,
+                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         edges.group_by_source()
         q = _linear(x, self.lin_q_node)
         kv_node = _fused_linear(x, self.lin_k_node, self.lin_v_node)
@@ -64,10 +64,10 @@ class GlobalInteractorLayer(nn.Module):
                            perm_by_src=edges.perm_by_src, tag=type(self).__name__,
                            padded=edges.count is not None)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(x, self.lin_hh, self.lin_self))
-        return self.proj_drop(_linear(upd, self.out_proj))
+        return _linear(upd, self.out_proj, drop=self.proj_drop, residual=residual)
 
-    def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
-        return _feed_forward(self.mlp, x)
+    def _ff_block(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return _feed_forward(self.mlp, x, residual)
 
 
 class GlobalInteractor(nn.Module):

@@ -105,13 +105,18 @@ def _fused_linear(x: torch.Tensor, a: nn.Linear, b: nn.Linear) -> torch.Tensor:
     return ops.fused_linear(x, torch.cat([a.weight, b.weight], dim=0), torch.cat([a.bias, b.bias], dim=0))
 
 
-def _linear(x: torch.Tensor, lin: nn.Linear, relu: bool = False) -> torch.Tensor:
-    return ops.fused_linear(x, lin.weight, lin.bias, relu=relu)
+def _linear(x: torch.Tensor, lin: nn.Linear, relu: bool = False, drop: Optional[nn.Dropout] = None,
+            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[residual +] [drop]([relu](lin(x)))`` in one launch."""
+    if drop is None:
+        return ops.fused_linear(x, lin.weight, lin.bias, relu=relu, residual=residual)
+    return ops.fused_linear(x, lin.weight, lin.bias, relu=relu, dropout_p=drop.p, training=drop.training,
+                            residual=residual)
 
 
-def _feed_forward(mlp: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    """Linear, ReLU, Dropout, Linear, Dropout (``local_encoder.py:117-122``) with the ReLU fused."""
-    return mlp[4](_linear(mlp[2](_linear(x, mlp[0], relu=True)), mlp[3]))
+def _feed_forward(mlp: nn.Sequential, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[residual +]`` Linear, ReLU, Dropout, Linear, Dropout (``local_encoder.py:117-122``): two launches."""
+    return _linear(_linear(x, mlp[0], relu=True, drop=mlp[2]), mlp[3], drop=mlp[4], residual=residual)
 
 
 class _EdgeAttentionBase(nn.Module):
@@ -136,18 +141,20 @@ class _EdgeAttentionBase(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim * 4), nn.ReLU(inplace=True), nn.Dropout(dropout),
                                  nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
 
-    def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet) -> torch.Tensor:
-        """message (Q.K, segment softmax, weighting) + aggregate + update + out_proj for per-edge
-        embeddings already in CSR order (``local_encoder.py:174-188,197-199`` / ``:364-379,391-394``)."""
+    def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet,
+                           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``[residual +]`` message (Q.K, segment softmax, weighting) + aggregate + update + out_proj +
+        dropout for per-edge embeddings already in CSR order (``local_encoder.py:174-188,197-199`` /
+        ``:364-379,391-394``)."""
         kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
         q = _linear(center, self.lin_q)
         agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            tag=type(self).__name__, padded=edges.count is not None)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(center, self.lin_hh, self.lin_self))
-        return self.proj_drop(_linear(upd, self.out_proj))
+        return _linear(upd, self.out_proj, drop=self.proj_drop, residual=residual)
 
-    def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
-        return _feed_forward(self.mlp, x)
+    def _ff_block(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return _feed_forward(self.mlp, x, residual)
 
 
 class AAEncoder(_EdgeAttentionBase):
@@ -188,15 +195,15 @@ class AAEncoder(_EdgeAttentionBase):
             rot_mod = x.shape[0]
         if edges is None:
             edges = _edge_set_from_coo(edge_index, edge_attr, x.shape[0], x.shape[0])
-        center = center + self._mha_block(ops.layer_norm(center, self.norm1), x, edges, rotate_mat, rot_mod)
-        center = center + self._ff_block(ops.layer_norm(center, self.norm2))
-        return center
+        # the residual additions are part of the last launch of each block
+        center = self._mha_block(ops.layer_norm(center, self.norm1), x, edges, rotate_mat, rot_mod, residual=center)
+        return self._ff_block(ops.layer_norm(center, self.norm2), residual=center)
 
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
-                   rot_mod: int) -> torch.Tensor:
+                   rot_mod: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         feat, _src, _dst = ops.edge_gather_rotate(x, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
                                                   edges.perm, rot_mod, edges.count)
-        return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges)
+        return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges, residual)
 
 
 class ALEncoder(_EdgeAttentionBase):
@@ -222,12 +229,12 @@ class ALEncoder(_EdgeAttentionBase):
             edges = _edge_set_from_coo(edge_index, edge_attr, x_lane.shape[0], x_actor.shape[0])
         # one code per lane for the three categorical attributes, one table row per code
         code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
-        x_actor = x_actor + self._mha_block(ops.layer_norm(x_actor, self.norm1), x_lane, edges, code, rotate_mat)
-        x_actor = x_actor + self._ff_block(ops.layer_norm(x_actor, self.norm2))
-        return x_actor
+        x_actor = self._mha_block(ops.layer_norm(x_actor, self.norm1), x_lane, edges, code, rotate_mat,
+                                  residual=x_actor)
+        return self._ff_block(ops.layer_norm(x_actor, self.norm2), residual=x_actor)
 
     def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
-                   rotate_mat: Optional[torch.Tensor]) -> torch.Tensor:
+                   rotate_mat: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         feat, src_csr, _dst = ops.edge_gather_rotate(x_lane, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
                                                      edges.perm, x_actor.shape[0], edges.count)
         table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
@@ -235,7 +242,8 @@ class ALEncoder(_EdgeAttentionBase):
         # the 12-row table is added per edge inside the embedding's second launch (row picked by the
         # lane's code); its gradient is a per-code sum of rows, not E*D contended atomic adds
         code_per_edge = lane_code.to(torch.int32).index_select(0, src_csr)
-        return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, table, code_per_edge), edges)
+        return self._attend_and_update(x_actor, self.lane_embed.forward_packed(feat, table, code_per_edge), edges,
+                                       residual)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -255,32 +263,36 @@ class TemporalEncoderLayer(nn.Module):
         self.dropout1 = nn.Dropout(dropout)
         self.dropout2 = nn.Dropout(dropout)
 
-    def _sa_block(self, x: torch.Tensor) -> torch.Tensor:
-        # causal self-attention over the time axis; x is [S, N, D]
+    def _sa_block(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        # residual + dropout1(out_proj(causal self-attention over the time axis)); x is [S, N, D]
         mha = self.self_attn
         S, N, D = x.shape
         H = mha.num_heads
         if x.is_cuda and ops.temporal_attention_supported(S, D, H):
             qkv = ops.fused_linear(x, mha.in_proj_weight, mha.in_proj_bias)
             o = ops.temporal_attention(qkv, H, mha.dropout, self.training)
-            return self.dropout1(ops.fused_linear(o, mha.out_proj.weight, mha.out_proj.bias))
+            return ops.fused_linear(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p,
+                                    training=self.training, residual=residual)
         # stock path (CPU tensors, unsupported shapes): fused SDPA kernel of the framework
         qkv = F.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(S, N, 3, H, D // H)
         q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))  # [N, H, S, d]
         o = F.scaled_dot_product_attention(q, k, v, dropout_p=mha.dropout if self.training else 0.0, is_causal=True)
         o = o.permute(2, 0, 1, 3).reshape(S, N, D)
-        return self.dropout1(mha.out_proj(o))
+        return residual + self.dropout1(mha.out_proj(o))
 
-    def _ff(self, x: torch.Tensor) -> torch.Tensor:
+    def _ff(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        # residual + dropout2(linear2(dropout(relu(linear1(x)))))
         if x.is_cuda:
-            h = ops.fused_linear(x, self.linear1.weight, self.linear1.bias, relu=True)
-            return ops.fused_linear(self.dropout(h), self.linear2.weight, self.linear2.bias)
-        return self.linear2(self.dropout(F.relu(self.linear1(x))))
+            h = ops.fused_linear(x, self.linear1.weight, self.linear1.bias, relu=True, dropout_p=self.dropout.p,
+                                 training=self.training)
+            return ops.fused_linear(h, self.linear2.weight, self.linear2.bias, dropout_p=self.dropout2.p,
+                                    training=self.training, residual=residual)
+        return residual + self.dropout2(self.linear2(self.dropout(F.relu(self.linear1(x)))))
 
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
-        x = src + self._sa_block(ops.layer_norm(src, self.norm1))
-        return x + self.dropout2(self._ff(ops.layer_norm(x, self.norm2)))
+        x = self._sa_block(ops.layer_norm(src, self.norm1), src)
+        return self._ff(ops.layer_norm(x, self.norm2), x)
 
 
 class _EncoderStack(nn.Module):

@@ -469,7 +469,7 @@ def linear_fused_supported(n_out: int, layer_norm: bool) -> bool:
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index):
+    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index, dropout_p, seed, residual):
         _need_gpu(x, weight)
         lead = x.shape[:-1]
         x2 = _rows2(x)
@@ -484,6 +484,15 @@ class _FusedLinear(torch.autograd.Function):
             if add is None or add_index.dtype != torch.int32 or add_index.shape != (m,):
                 raise ValueError("add_index must be an int32 vector with one entry per row, next to a table in `add`")
             add_index = add_index.contiguous()
+        res2 = None
+        if residual is not None:
+            res2 = _rows2(residual)
+            if res2.shape != (m, n):
+                raise ValueError(f"residual {tuple(residual.shape)} does not match the output [{m}, {n}]")
+        if ln and (dropout_p > 0.0 or residual is not None):
+            raise ValueError("dropout / residual are available for the plain epilogues only")
+        if relu and residual is not None:
+            raise ValueError("a residual after a ReLU epilogue is not supported (the ReLU mask is read off the output)")
         y = torch.empty(m, n, dtype=torch.float32, device=x.device)
         z = torch.empty(m, n, dtype=torch.float32, device=x.device) if ln else None
         stats = torch.empty(m, 2, dtype=torch.float32, device=x.device) if ln else None
@@ -494,17 +503,21 @@ class _FusedLinear(torch.autograd.Function):
         _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias_c), _p(add2),
                   add2.stride(0) if add2 is not None else 0, _p(add_index),
                   add2.shape[0] if add_index is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi,
+                  float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(res2), res2.stride(0) if res2 is not None else 0,
                   m, n, k, _p(y), n, _p(z), n, _p(stats), _stream(x))
-        ctx.save_for_backward(x2, w2, z, stats, gamma_c, beta_c, y if (relu and not ln) else None, add_index)
+        need_y = relu and not ln  # the ReLU (and, with it, the dropout) mask is read off the output
+        ctx.save_for_backward(x2, w2, z, stats, gamma_c, beta_c, y if need_y else None, add_index,
+                              DEVICE_SEED if dropout_p > 0.0 else None)
         ctx.cfg = (bool(relu), ln, tuple(lead), bias is not None, add is not None,
-                   tuple(add.shape) if add is not None else None)
+                   tuple(add.shape) if add is not None else None, float(dropout_p), int(seed),
+                   tuple(residual.shape) if residual is not None else None)
         return y.view(*lead, n)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, w2, z, stats, gamma, beta, y_relu, add_index = ctx.saved_tensors
-        relu, ln, lead, has_bias, has_add, add_shape = ctx.cfg
+        x2, w2, z, stats, gamma, beta, y_relu, add_index, seed_dev = ctx.saved_tensors
+        relu, ln, lead, has_bias, has_add, add_shape, dropout_p, seed, res_shape = ctx.cfg
         m, k = x2.shape
         n = w2.shape[0]
         dev = x2.device
@@ -518,6 +531,10 @@ class _FusedLinear(torch.autograd.Function):
             ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
             _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), n, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
                       _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+        elif dropout_p > 0.0:
+            dz = torch.empty(m, n, dtype=torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), _p(y_relu), n, int(relu), dropout_p, seed,
+                      _p(seed_dev), m, n, _p(dz), n, s)
         elif relu:
             dz = torch.ops.aten.threshold_backward(dy2, y_relu, 0.0)  # dy where y > 0, one launch
         else:
@@ -543,7 +560,8 @@ class _FusedLinear(torch.autograd.Function):
                 ws = _workspace(_lib.query("hivt_rowsum_by_code_workspace_bytes", m, n, codes), dev)
                 _lib.call("hivt_rowsum_by_code", _p(dz), dz.stride(0), _p(add_index), m, n, codes, _p(dadd), _p(ws),
                           ws.numel(), s)
-        return dx, dw, db, dadd, dgamma, dbeta, None, None, None
+        dres = dy.reshape(res_shape) if (res_shape is not None and ctx.needs_input_grad[11]) else None
+        return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -589,26 +607,33 @@ def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
 
 def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  add: Optional[torch.Tensor] = None, layer_norm: Optional[torch.nn.LayerNorm] = None,
-                 relu: bool = False, add_index: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``[relu]([layer_norm](x @ weight.T + bias [+ add]))`` in one launch (exact fp32 on the matrix cores).
-    With ``add_index`` (int32, one entry per row) ``add`` is a small table [codes <= 16, N] and row m adds
-    ``add[add_index[m]]``.
+                 relu: bool = False, add_index: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
+                 training: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[residual +] [dropout]([relu]([layer_norm](x @ weight.T + bias [+ add])))`` in one launch (exact
+    fp32 on the matrix cores).  With ``add_index`` (int32, one entry per row) ``add`` is a small table
+    [codes <= 16, N] and row m adds ``add[add_index[m]]``.  Dropout (active when ``training``) and the
+    residual are part of the plain epilogues only (no ``layer_norm``).
 
     Falls back to the stock GPU ops only where no kernel exists for the shape (LayerNorm wider than
     128 columns); CPU tensors are refused."""
     _need_gpu(x, weight)
     n = weight.shape[0]
+    p = float(dropout_p) if training else 0.0
     if not linear_fused_supported(n, layer_norm is not None):
         y = torch.nn.functional.linear(x, weight, bias)
         if add is not None:
             y = y + (add if add_index is None else add.index_select(0, add_index.long()))
         if layer_norm is not None:
             y = layer_norm(y)
-        return torch.relu(y) if relu else y
+        y = torch.relu(y) if relu else y
+        if p > 0.0:
+            y = torch.nn.functional.dropout(y, p, True)
+        return y if residual is None else residual + y
     gamma = layer_norm.weight if layer_norm is not None else None
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0
-    return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps, add_index)
+    return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps, add_index, p,
+                              _fresh_seed() if p > 0.0 else 0, residual)
 
 
 # --------------------------------------------------------------------------------------------

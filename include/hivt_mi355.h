@@ -209,14 +209,26 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
  * categorical lane embeddings enter (models/local_encoder.py:349-357).  Epilogues: none, ReLU,
  * LayerNorm(gamma, beta, eps) and LayerNorm + ReLU (N <= 128); the LayerNorm epilogues also write
  * the pre-normalisation values z (optional) and per-row (mean, rstd) into stats [M,2].
+ * The plain epilogues (none, ReLU) can finish with y = residual + dropout(.) (dropout_p in [0,1), mask
+ * from a counter-based generator keyed on (seed [+ *seed_ptr], row * N + col); residual [M,N] or NULL),
+ * which is the "x + Dropout(Linear(.))" tail of every attention and feed-forward block
+ * (models/local_encoder.py:168-169,193-202,268-280).
  * Replaces nn.Linear / nn.LayerNorm / nn.ReLU chains of the per-edge embedding MLPs
  * (models/embedding.py:15-23,36-46), the K|V / Q / update / output projections
  * (models/local_encoder.py:106-113, models/global_interactor.py:79-88) and the feed-forward blocks
  * (models/local_encoder.py:117-122). */
 int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
                     const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
-                    const float* gamma, const float* beta, float eps, int epilogue, int64_t M, int32_t N, int32_t K, float* y,
-                    int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream);
+                    const float* gamma, const float* beta, float eps, int epilogue, float dropout_p, uint64_t seed,
+                    const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N, int32_t K,
+                    float* y, int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream);
+
+/* Gradient through the dropout (and ReLU) of hivt_linear_fwd's plain epilogues:
+ * dz = dy * keep / (1 - dropout_p) [* (y > 0) when relu != 0; y is then the forward output and the mask
+ * is not regenerated], keep = the forward's mask recomputed from (seed [+ *seed_ptr], row * N + col). */
+int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
+                     uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz, int64_t dz_ld,
+                     hivt_stream_t stream);
 
 /* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue). */
 int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,

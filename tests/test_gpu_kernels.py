@@ -617,3 +617,40 @@ def test_fused_linear_with_table_rows_added(M, K, N, codes):
     fixed[0] = codes - 1
     ref2 = torch.relu(norm(lin(x) + table.index_select(0, fixed.long())))
     close(y2, ref2, 1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_fused_linear_dropout_and_residual_epilogue(relu):
+    """y = residual + dropout([relu](x W^T + b)): the kept fraction, the kept values, and gradients that
+    use exactly the forward's mask (read back from the output and replayed through the framework)."""
+    gen = torch.Generator().manual_seed(31 + relu)
+    M, K, N, p = 3001, 128, 256, 0.3
+    x = torch.randn(M, K, generator=gen).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    res = None if relu else torch.randn(M, N, generator=gen).to(DEV).requires_grad_(True)
+    go = torch.randn(M, N, generator=gen).to(DEV)
+    torch.manual_seed(9)
+    y = ops.fused_linear(x, lin.weight, lin.bias, relu=relu, dropout_p=p, training=True, residual=res)
+    inputs = (x, lin.weight, lin.bias) + (() if res is None else (res,))
+    got = torch.autograd.grad(y, inputs, go)
+    with torch.no_grad():
+        pre = lin(x)
+        pre = torch.relu(pre) if relu else pre
+        delta = y if res is None else y - res
+        live = pre.abs() > 1e-6  # where the pre-dropout value is not (numerically) zero the mask is visible
+        kept = (delta.abs() > 0) & live
+        frac = 1.0 - kept[live].float().mean().item()
+        assert abs(frac - p) < 0.01, frac
+        close(delta[kept], (pre / (1 - p))[kept], 1e-5, atol=1e-5)
+        mask = torch.where(live, kept, torch.ones_like(kept)).float() / (1 - p)
+    ref = lin(x)
+    ref = (torch.relu(ref) if relu else ref) * mask
+    if res is not None:
+        ref = ref + res
+    want = torch.autograd.grad(ref, inputs, go)
+    for a, b in zip(got, want):
+        close(a, b, 1e-4, atol=2e-5)
+    # evaluation mode: no dropout
+    y_eval = ops.fused_linear(x, lin.weight, lin.bias, relu=relu, dropout_p=p, training=False, residual=res)
+    ref_eval = torch.relu(lin(x)) if relu else lin(x) + res
+    close(y_eval, ref_eval, 1e-5, atol=1e-5)
