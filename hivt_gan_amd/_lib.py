@@ -94,15 +94,34 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+_functions = {}
+
+
+def _function(name: str):
+    fn = _functions.get(name)
+    if fn is None:
+        fn = _functions[name] = getattr(load(), name)
+    return fn
+
+
 def call(name: str, *args) -> None:
     """Invoke an ``int``-returning entry point and raise on a non-zero return code."""
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    rc = _function(name)(*args)
     if rc != 0:
-        msg = lib.hivt_last_error().decode("utf-8", "replace")
+        msg = load().hivt_last_error().decode("utf-8", "replace")
         raise HivtLibraryError(f"{name} failed with code {rc}: {msg}")
 
 
+_sizes = {}
+
+
 def query(name: str, *args) -> int:
-    """Invoke a size query (``*_workspace_bytes``) or ``hivt_version``."""
-    return int(getattr(load(), name)(*args))
+    """Invoke a size query (``*_workspace_bytes``) or ``hivt_version``; answers are pure functions of the
+    arguments and are remembered."""
+    key = (name, args)
+    size = _sizes.get(key)
+    if size is None:
+        if len(_sizes) > 4096:
+            _sizes.clear()
+        size = _sizes[key] = int(_function(name)(*args))
+    return size

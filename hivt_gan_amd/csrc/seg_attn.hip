@@ -6,7 +6,7 @@
 // so one wave instruction loads EPI = 64/LPR edges (2 at D=128, 4 at D=64) as full 512-byte /
 // 256-byte contiguous rows.  A head spans LPH = D/(4H) adjacent lanes; the QK dot is finished with
 // log2(LPH) xor-shuffles.  Each lane slot runs an online softmax over its share of the row's edges
-// (4 edges in flight per slot), slots are merged with xor-shuffles, and for long rows the 4 waves
+// (4 edges in flight per slot, 2 in short-row mode), slots are merged with xor-shuffles, and for long rows the 4 waves
 // of a block split one row and merge through LDS.  No atomics: every target row is owned by one
 // wave or one block, so results are deterministic.
 #include "common.h"
@@ -18,7 +18,8 @@ namespace hivt {
 namespace {
 
 constexpr float kNegSentinel = -1.0e30f;  // "no edge seen yet"; exp(kNegSentinel - x) == 0
-constexpr int kUnroll = 4;
+constexpr int kUnrollLong = 4;   // edges in flight per lane slot
+constexpr int kUnrollShort = 2;  // short-row mode: rows average under two edges, a wider batch is mostly masked work
 
 struct SegAttnArgs {
   const float* q;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
   constexpr int RPW = SPLIT ? EPI : 1;
+  constexpr int kUnroll = SPLIT ? kUnrollShort : kUnrollLong;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
 
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? EPI : 1;
+  constexpr int kUnroll = SPLIT ? kUnrollShort : kUnrollLong;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
 

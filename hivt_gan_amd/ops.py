@@ -16,13 +16,15 @@ from . import _lib
 
 
 def _p(t: Optional[torch.Tensor], byte_offset: int = 0):
+    """Device address as a plain integer (what a ``c_void_p`` parameter converts fastest from)."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr() + byte_offset)
+    return t.data_ptr() + byte_offset
 
 
 def _stream(t: torch.Tensor):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """Raw handle of the calling thread's current stream on ``t``'s device."""
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
 def _need_gpu(*tensors: torch.Tensor) -> None:

@@ -44,3 +44,17 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
 ev = prof.key_averages()
 print(f"ops/step {sum(e.count for e in ev) / 3:.0f}, device time {sum(e.self_device_time_total for e in ev) / 3e3:.2f} ms/step")
 print(ev.table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+
+# Python-level view (backward moved onto the calling thread so that the profiler sees it)
+import cProfile
+import pstats
+
+with torch.autograd.set_multithreading_enabled(False):
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(5):
+        step(i)
+    pr.disable()
+    torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(45)
