@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void temporal_attn_fwd_kernel(const TAttnArgs 
       float p = fexp(s - mn);
       l = l * corr + p;
       if (drop) {
-        const uint64_t idx = (((uint64_t)n * a.H + h) * kMaxS + i) * kMaxS + j;
-        p = uniform01(seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
+        const uint32_t idx = (((uint32_t)n * a.H + h) * kMaxS + i) * kMaxS + j;
+        p = uniform01_u32(seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
       }
 #pragma unroll
       for (int x = 0; x < HD; ++x) acc[x] = acc[x] * corr + p * vr[x];
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
   const int S = a.S, N = a.N, H = a.H;
   float* qkv = lds;                 // [S][3D]
   float* go = lds + S * ROW;        // [S][D]   dO
-  float* oo = go + S * D;           // [S][D]   O (forward output)
-  float* aux = oo + S * D;          // [H][kMaxS][2]  lse, delta per (head, query)
+  float* aux = go + S * D;          // [H][kMaxS][2]  lse, delta per (head, query)
+  uint32_t* keep_bits = reinterpret_cast<uint32_t*>(aux + H * kMaxS * 2);  // [H][kMaxS]: bit j = score (i, j) kept
   for (int i = threadIdx.x; i < S * (ROW / 4); i += 256) {
     const int s = i / (ROW / 4), c = (i % (ROW / 4)) * 4;
     *reinterpret_cast<float4*>(qkv + s * ROW + c) =
@@ -108,22 +108,38 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
   for (int i = threadIdx.x; i < S * (D / 4); i += 256) {
     const int s = i / (D / 4), c = (i % (D / 4)) * 4;
     *reinterpret_cast<float4*>(go + s * D + c) = *reinterpret_cast<const float4*>(a.d_out + ((int64_t)s * N + n) * D + c);
-    *reinterpret_cast<float4*>(oo + s * D + c) = *reinterpret_cast<const float4*>(a.out + ((int64_t)s * N + n) * D + c);
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < H * kMaxS; t += 256) {
-    const int h = t / kMaxS, i = t % kMaxS;
-    if (i >= S) continue;
-    float d = 0.0f;
-#pragma unroll
-    for (int x = 0; x < HD; ++x) d += go[i * D + h * HD + x] * oo[i * D + h * HD + x];
-    aux[(h * kMaxS + i) * 2 + 0] = a.lse[((int64_t)n * H + h) * S + i];
-    aux[(h * kMaxS + i) * 2 + 1] = d;
   }
   __syncthreads();
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
   const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
+  for (int t = threadIdx.x; t < H * kMaxS; t += 256) {
+    const int h = t / kMaxS, i = t % kMaxS;
+    if (i >= S) continue;
+    // delta = dO . O over the head's slice; O is read once, straight from global memory (keeping it out
+    // of LDS is what lets a third block share the compute unit)
+    float d = 0.0f;
+    const float* orow = a.out + ((int64_t)i * N + n) * D + h * HD;
+#pragma unroll
+    for (int x = 0; x < HD; x += 4) {
+      const float4 o4 = *reinterpret_cast<const float4*>(orow + x);
+      d += go[i * D + h * HD + x] * o4.x + go[i * D + h * HD + x + 1] * o4.y + go[i * D + h * HD + x + 2] * o4.z +
+           go[i * D + h * HD + x + 3] * o4.w;
+    }
+    aux[(h * kMaxS + i) * 2 + 0] = a.lse[((int64_t)n * H + h) * S + i];
+    aux[(h * kMaxS + i) * 2 + 1] = d;
+    // the forward's dropout decisions of query i, drawn once and shared by both roles below
+    uint32_t bits = 0xffffffffu;
+    if (drop) {
+      bits = 0u;
+      for (int j = 0; j <= i; ++j) {
+        const uint32_t idx = (((uint32_t)n * H + h) * kMaxS + i) * kMaxS + j;
+        bits |= (uniform01_u32(seed, idx) >= a.dropout_p ? 1u : 0u) << j;
+      }
+    }
+    keep_bits[h * kMaxS + i] = bits;
+  }
+  __syncthreads();
   // Every thread owns index r of head h twice: as a QUERY (dQ_r) and as a KEY (dK_r, dV_r).
   // A pass covers 256 / kMaxS whole heads; all threads run every pass so that the barrier between
   // the last read and the in-place overwrite of a pass's q|k|v slots is reached by everyone.
@@ -146,6 +162,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
       }
       // as query r over keys j <= r
       const float lse_r = aux[(h * kMaxS + r) * 2], delta_r = aux[(h * kMaxS + r) * 2 + 1];
+      const uint32_t bits_r = keep_bits[h * kMaxS + r];
       for (int j = 0; j <= r; ++j) {
         const float* kj = qkv + j * ROW + D + h * HD;
         const float* vj = qkv + j * ROW + 2 * D + h * HD;
@@ -156,17 +173,16 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
           dp += gr[x] * vj[x];
         }
         const float p = fexp(s * a.scale - lse_r);
-        float ms = 1.0f;
-        if (drop) {
-          const uint64_t idx = (((uint64_t)n * H + h) * kMaxS + r) * kMaxS + j;
-          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
-        }
+        const float ms = ((bits_r >> j) & 1u) ? keep_scale : 0.0f;
         const float ds = p * (dp * ms - delta_r) * a.scale;
 #pragma unroll
         for (int x = 0; x < HD; ++x) dq[x] += ds * kj[x];
       }
-      // as key r over queries i >= r
-      for (int i = r; i < S; ++i) {
+      // as key r over queries i >= r.  Every lane walks ALL queries in the same order and masks the
+      // ones before its key: the lanes of a head then read one LDS address per step (a broadcast),
+      // where per-lane start rows would hit one bank S ways (row pitch 3D is a multiple of 64 words).
+      for (int i = 0; i < S; ++i) {
+        if (i < r) continue;
         const float* qi = qkv + i * ROW + h * HD;
         const float* gi = go + i * D + h * HD;
         float s = 0.0f, dp = 0.0f;
@@ -176,11 +192,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
           dp += gi[x] * vr[x];
         }
         const float p = fexp(s * a.scale - aux[(h * kMaxS + i) * 2]);
-        float ms = 1.0f;
-        if (drop) {
-          const uint64_t idx = (((uint64_t)n * H + h) * kMaxS + i) * kMaxS + r;
-          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
-        }
+        const float ms = ((keep_bits[h * kMaxS + i] >> r) & 1u) ? keep_scale : 0.0f;
         const float ds = p * (dp * ms - aux[(h * kMaxS + i) * 2 + 1]) * a.scale;
         const float pm = p * ms;
 #pragma unroll
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
 template <int D, int HD>
 int launch(bool backward, const TAttnArgs& a, hipStream_t stream) {
   const size_t fwd_lds = (size_t)a.S * 3 * D * sizeof(float);
-  const size_t bwd_lds = ((size_t)a.S * 5 * D + (size_t)a.H * kMaxS * 2) * sizeof(float);
+  const size_t bwd_lds = ((size_t)a.S * 4 * D + (size_t)a.H * kMaxS * 3) * sizeof(float);
   const size_t need = backward ? bwd_lds : fwd_lds;
   if (need > 160 * 1024) return -1;
   if (need > 48 * 1024) {
@@ -243,6 +255,8 @@ int check(const char* what, int32_t S, int32_t N, int32_t D, int32_t H, float p)
   HIVT_REQUIRE(N >= 0 && H >= 1 && D % H == 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(H * kMaxS % 256 == 0 || H * kMaxS <= 256, HIVT_ERR_ARG, "%s: unsupported head count %d", what, H);
   HIVT_REQUIRE(p >= 0.0f && p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  HIVT_REQUIRE((int64_t)N * H * kMaxS * kMaxS < ((int64_t)1 << 32), HIVT_ERR_ARG,
+               "%s: %d agents x %d heads exceed the 32-bit dropout index", what, N, H);
   return HIVT_OK;
 }
 
