@@ -294,6 +294,40 @@ class TemporalEncoderLayer(nn.Module):
         x = self._sa_block(ops.layer_norm(src, self.norm1), src)
         return self._ff(ops.layer_norm(x, self.norm2), x)
 
+    def forward_last(self, src: torch.Tensor) -> torch.Tensor:
+        """Row ``[-1]`` of ``forward(src)`` ([N, D]) without computing the other rows.  The last position
+        attends to every step, so keys and values are still projected for the whole sequence, but the
+        query, the output projection, the feed-forward block and both residuals exist for one row per
+        agent only -- the encoder's caller reads nothing else of its last layer
+        (``models/local_encoder.py:241``)."""
+        mha = self.self_attn
+        S, N, D = src.shape
+        H, hd = mha.num_heads, D // mha.num_heads
+        xn = ops.layer_norm(src, self.norm1)
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        gpu = src.is_cuda
+
+        def lin(x, weight, bias, **kw):
+            if gpu:
+                return ops.fused_linear(x, weight, bias, **kw)
+            y = F.linear(x, weight, bias)
+            if kw.get("relu"):
+                y = F.relu(y)
+            y = F.dropout(y, kw.get("dropout_p", 0.0), kw.get("training", False))
+            return y if kw.get("residual") is None else kw["residual"] + y
+
+        q = lin(xn[-1], w[:D], b[:D]).view(1, N, H, hd)
+        kv = lin(xn, w[D:], b[D:]).view(S, N, 2, H, hd)
+        scores = (kv[:, :, 0] * q).sum(dim=-1) * (hd ** -0.5)             # [S, N, H]
+        prob = F.dropout(torch.softmax(scores, dim=0), mha.dropout, self.training)
+        o = (prob.unsqueeze(-1) * kv[:, :, 1]).sum(dim=0).reshape(N, D)
+        x = lin(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p, training=self.training,
+                residual=src[-1])
+        h = lin(ops.layer_norm(x, self.norm2), self.linear1.weight, self.linear1.bias, relu=True,
+                dropout_p=self.dropout.p, training=self.training)
+        return lin(h, self.linear2.weight, self.linear2.bias, dropout_p=self.dropout2.p, training=self.training,
+                   residual=x)
+
 
 class _EncoderStack(nn.Module):
     """``layers`` + final ``norm`` under the key names of ``nn.TransformerEncoder``."""
@@ -307,6 +341,12 @@ class _EncoderStack(nn.Module):
         for layer in self.layers:
             x = layer(x)
         return ops.layer_norm(x, self.norm)
+
+    def forward_last(self, x: torch.Tensor) -> torch.Tensor:
+        """``forward(x)[-1]``: the last layer and the final norm run for the last position only."""
+        for layer in self.layers[:-1]:
+            x = layer(x)
+        return ops.layer_norm(self.layers[-1].forward_last(x), self.norm)
 
 
 class TemporalEncoder(nn.Module):
@@ -327,7 +367,7 @@ class TemporalEncoder(nn.Module):
     def forward(self, x: torch.Tensor, padding_mask: torch.Tensor) -> torch.Tensor:
         x = torch.where(padding_mask.t().unsqueeze(-1), self.padding_token, x)
         x = torch.cat((x, self.cls_token.expand(-1, x.shape[1], -1)), dim=0) + self.pos_embed
-        return self.transformer_encoder(x)[-1]
+        return self.transformer_encoder.forward_last(x)
 
     @staticmethod
     def generate_square_subsequent_mask(seq_len: int) -> torch.Tensor:

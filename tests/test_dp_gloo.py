@@ -132,7 +132,10 @@ def test_two_rank_step_matches_manual_average(tmp_path, poison_rank):
     for group in ("critic", "generator"):
         assert dp[group].shape == ref[group].shape
         assert float(ref[group].abs().max()) > 0
-        assert torch.allclose(dp[group], ref[group], rtol=1e-5, atol=1e-7), f"{group} gradients differ"
+        # the two sides sum in different orders (worker processes run other thread counts than this
+        # one), so agreement is judged against the scale of the gradient vector
+        err = float((dp[group] - ref[group]).abs().max())
+        assert err <= 1e-6 * float(ref[group].abs().max()), f"{group} gradients differ by {err:.3e}"
 
 
 def test_flat_bucket_packs_and_hands_back_views():

@@ -374,3 +374,22 @@ def test_critic_spectral_norm_kernel_matches_framework_hook(training):
             assert_close(m.weight_orig.grad, lin.weight_orig.grad, 2e-5, msg="d weight_orig")
             assert_close(m.bias.grad, lin.bias.grad, 2e-5, msg="d bias")
         assert_close(xa.grad, xb.grad, 2e-5, msg="d input")
+
+
+def test_temporal_last_position_equals_full_layer_row():
+    """The last layer evaluated for the last position only gives row [-1] of the full evaluation, and the
+    same gradients for every parameter and for the input sequence."""
+    torch.manual_seed(3)
+    layer = hv.TemporalEncoderLayer(embed_dim=128, num_heads=8, dropout=0.0).to(DEV)
+    src = torch.randn(21, 500, 128, device=DEV, requires_grad=True)
+    go = torch.randn(500, 128, device=DEV)
+    full = layer(src)[-1]
+    g_full = torch.autograd.grad(full, [src] + list(layer.parameters()), go, allow_unused=True)
+    last = layer.forward_last(src)
+    g_last = torch.autograd.grad(last, [src] + list(layer.parameters()), go, allow_unused=True)
+    assert_close(last, full, 1e-5, msg="last row")
+    names = ["src"] + [k for k, _ in layer.named_parameters()]
+    for k, a, b in zip(names, g_last, g_full):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert_close(a, b, 3e-5, msg=k)
