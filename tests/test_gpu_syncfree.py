@@ -150,3 +150,44 @@ def test_edge_capacity_overflow_discards_the_batch():
     assert tr.overflowed_steps() == 2
     for k, v in model.named_parameters():
         assert torch.equal(v, before[k]), k
+
+
+def test_bucketed_all_reduce_path_on_gpu_single_rank():
+    """The data-parallel path (flat buckets, RCCL all-reduce, device-side zeroing of a discarded batch)
+    with a world of one rank must reproduce the plain step; a poisoned batch must leave the model
+    untouched... except through the averaged (all-zero) gradient, which AdamW turns into pure weight
+    decay on the generator -- so that case is checked on the reduced buffers instead."""
+    import torch.distributed as dist
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=DEV)
+    try:
+        batches = [hv.make_batch(4, first_index=600 + 4 * i).to(DEV) for i in range(2)]
+        base = small_model()
+        spec = hv.GanTrainer.calibrate(base, batches)
+        plain_model, dp_model = copy.deepcopy(base), copy.deepcopy(base)
+        plain = hv.GanTrainer(plain_model, distributed=False, edge_capacity=spec.edge_capacity)
+        dp = hv.GanTrainer(dp_model, distributed=True, edge_capacity=spec.edge_capacity)
+        assert set(dp.buckets) == {"generator", "critic"}
+        for i in (0, 1, 0):
+            la, lb = plain.step(batches[i].clone()), dp.step(batches[i].clone())
+            for k in ("reg_loss", "cls_loss", "d_loss", "g_total"):
+                assert rel_err(lb[k], la[k]) < 1e-4, (i, k)
+        noise_only = ("lin_k.bias", "lin_k_node.bias", "lin_k_edge.bias", "in_proj_bias", "pi.6.bias")
+        pa, pb = dict(plain_model.named_parameters()), dict(dp_model.named_parameters())
+        for k in pa:
+            if not k.endswith(noise_only):
+                assert float((pa[k] - pb[k]).detach().abs().max()) < 2e-4, k
+        poisoned = batches[0].clone()
+        poisoned["y"][0, 0, 0] = float("nan")
+        logs = dp.step(poisoned)
+        assert float(logs["skipped"]) == 1.0
+        for group in ("critic", "generator"):
+            flat = dp.buckets[group].flat
+            assert bool(torch.isfinite(flat).all()) and float(flat.abs().max()) == 0.0, group
+        assert all(bool(torch.isfinite(v).all()) for v in dp_model.parameters())
+    finally:
+        dist.destroy_process_group()
