@@ -41,8 +41,8 @@ SIGNATURES = {
     "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,
                                       _P, _P, c_int64, _P, c_int64, _P]),
     "hivt_linear_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int32, _P, _P, c_float, c_int, c_float,
-                                c_uint64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P,
-                                _P]),
+                                c_float, c_uint64, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, _P,
+                                c_int64, _P, _P]),
     "hivt_dropout_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_uint64, _P, c_int64, c_int32, _P,
                                  c_int64, _P]),
     "hivt_rowsum_by_code_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
@@ -65,6 +65,12 @@ SIGNATURES = {
     "hivt_embed2_fwd": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P]),
     "hivt_embed2_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_embed2_bwd": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P, _P,
+                                c_size_t, _P]),
+    "hivt_critic_saved_floats": (c_size_t, [c_int64, c_int32, _P, c_int32]),
+    "hivt_critic_workspace_bytes": (c_size_t, [c_int64, c_int32, _P]),
+    "hivt_critic_fwd": (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_float, c_float, c_uint64, _P, c_int32, _P,
+                                _P, _P, _P]),
+    "hivt_critic_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                 c_size_t, _P]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -123,5 +129,6 @@ def query(name: str, *args) -> int:
     if size is None:
         if len(_sizes) > 4096:
             _sizes.clear()
-        size = _sizes[key] = int(_function(name)(*args))
+        conv = [(ctypes.c_int32 * len(a))(*a) if isinstance(a, tuple) else a for a in args]  # tuples: int32 arrays
+        size = _sizes[key] = int(_function(name)(*conv))
     return size

@@ -72,15 +72,22 @@ class BaseTrajectoryCritic(nn.Module):
     def _spectral_layers(self) -> List[SpectralLinear]:
         return [m for m in self.mlp if isinstance(m, SpectralLinear)] + [self.out]
 
+    def _activation(self):
+        slope, drop = 0.01, 0.0
+        for mod in self.mlp:
+            if isinstance(mod, nn.LeakyReLU):
+                slope = mod.negative_slope
+            elif isinstance(mod, nn.Dropout):
+                drop = mod.p
+        return slope, drop
+
     def forward(self, traj: torch.Tensor) -> torch.Tensor:
         """traj [B, T, D] -> realism score [B]."""
+        if traj.is_cuda:
+            return self._scores_gpu(traj, False)
         h = traj.reshape(traj.shape[0], -1)
         layers = self._spectral_layers()
-        if h.is_cuda:
-            weights = ops.spectral_normalize([m.weight_orig for m in layers], [m.weight_u for m in layers],
-                                             [m.weight_v for m in layers], self.training, _EPS)
-        else:
-            weights = [m.normalized_weight() for m in layers]
+        weights = [m.normalized_weight() for m in layers]
         it = iter(zip(layers, weights))
         for mod in self.mlp:
             if isinstance(mod, SpectralLinear):
@@ -90,6 +97,26 @@ class BaseTrajectoryCritic(nn.Module):
                 h = mod(h)
         lin, w = next(it)
         return F.linear(h, w, lin.bias).squeeze(-1)
+
+    def _scores_gpu(self, traj: torch.Tensor, with_input_grad_norm: bool):
+        # two library calls: spectral normalisation of every layer, then the whole MLP
+        layers = self._spectral_layers()
+        weights = ops.spectral_normalize([m.weight_orig for m in layers], [m.weight_u for m in layers],
+                                         [m.weight_v for m in layers], self.training, _EPS)
+        slope, drop = self._activation()
+        return ops.critic_scores(traj, list(weights), [m.bias for m in layers], slope, drop, self.training,
+                                 with_input_grad_norm)
+
+    def scores_and_input_grad_norm(self, traj: torch.Tensor):
+        """``(score [B], ||d score_i / d traj_i||^2 [B])`` from one forward pass: the two quantities the
+        critic loss needs of the real samples (hinge term and R1 penalty, ``models/hivt.py:244-252``)."""
+        if traj.is_cuda:
+            return self._scores_gpu(traj, True)
+        r = traj.detach().clone().requires_grad_(True)
+        score = self(r)
+        (grad,) = torch.autograd.grad(outputs=score.sum(), inputs=r, create_graph=True, retain_graph=True,
+                                      only_inputs=True)
+        return score, grad.pow(2).reshape(grad.size(0), -1).sum(dim=1)
 
 
 class _HorizonCritic(BaseTrajectoryCritic):
@@ -101,6 +128,10 @@ class _HorizonCritic(BaseTrajectoryCritic):
 
     def forward(self, traj: torch.Tensor) -> torch.Tensor:
         return super().forward(traj[:, :self.horizon])
+
+    def scores_and_input_grad_norm(self, traj: torch.Tensor):
+        # the score does not depend on steps beyond the horizon, so neither does the gradient norm
+        return super().scores_and_input_grad_norm(traj[:, :self.horizon])
 
 
 class ShortScaleCritic(_HorizonCritic):

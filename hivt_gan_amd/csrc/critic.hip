@@ -1,0 +1,361 @@
+// One trajectory critic, whole passes per call.
+//
+// A critic is an MLP over B flattened trajectories: L hidden layers h_l = Dropout(LeakyReLU(h_{l-1} W_l^T
+// + b_l)) and a one-wide output layer D = h_L w_o^T + b_o (models/critics/base_critic.py:19-44).  The GAN
+// step calls each critic nine times and needs, for the real samples, the squared norm of dD/dx as a
+// differentiable quantity (R1 penalty, losses/adv_losses.py:36-47 and models/hivt.py:244-252).  Driven
+// from the framework that is several hundred small operator launches per step and a double backward.
+//
+// Here a forward (optionally with the input-gradient chain) or a backward is ONE host call that issues
+// the whole sequence of launches.  The R1 term needs no double backward: with the activation / dropout
+// factors c_l = d h_l / d z_l (piecewise constant, read off the sign of the stored h_l) the input
+// gradient is itself a short chain of products,
+//     G_L = w_o * c_L,   g_{l-1} = G_l W_l,   G_{l-1} = g_{l-1} * c_{l-1},   dD/dx = g_0,
+// whose gradient with respect to the weights is a second chain of the same shape:
+//     e_0 = d r / d g_0,   dW_l += G_l^T e_{l-1},   e_l = (e_{l-1} W_l^T) * c_l,   dw_o += colsum(e_L).
+// All products run on the fp32-MFMA linear kernels of this library.
+#include "common.h"
+
+#include <math.h>
+
+namespace hivt {
+namespace {
+
+constexpr int kMaxHidden = HIVT_CRITIC_MAX_LAYERS;  // hidden layers per critic
+
+// d h / d z of Dropout(LeakyReLU(z)) recovered from h: kept and positive, kept and negative, dropped.
+__device__ __forceinline__ float act_factor(float h, float keep_scale, float neg_slope) {
+  return h > 0.0f ? keep_scale : (h < 0.0f ? keep_scale * neg_slope : 0.0f);
+}
+
+// out[i][c] = (row ? row[i] : 1) * (vec ? vec[c] : 1) * (in ? in[i][c] : 1) * act_factor(h[i][c])
+__global__ __launch_bounds__(256) void masked_product_kernel(const float* __restrict__ in, const float* __restrict__ row,
+                                                             const float* __restrict__ vec,
+                                                             const float* __restrict__ h, float keep_scale,
+                                                             float neg_slope, int64_t B, int W,
+                                                             float* __restrict__ out) {
+  const int64_t total = B * (int64_t)W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / W;
+    const int c = (int)(i - r * W);
+    float v = act_factor(h[i], keep_scale, neg_slope);
+    if (in != nullptr) v *= in[i];
+    if (row != nullptr) v *= row[r];
+    if (vec != nullptr) v *= vec[c];
+    out[i] = v;
+  }
+}
+
+// out[i][c] = scale * row[i] * in[i][c]
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ in, const float* __restrict__ row,
+                                                        float scale, int64_t B, int W, float* __restrict__ out) {
+  const int64_t total = B * (int64_t)W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = scale * row[i / W] * in[i];
+}
+
+// out[i] = sum_c in[i][c]^2, one wave per row
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ in, int64_t B, int W,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < B; r += (int64_t)gridDim.x * 4) {
+    float s = 0.0f;
+    for (int c = lane; c < W; c += kWave) {
+      const float v = in[r * W + c];
+      s = fmaf(v, v, s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+  }
+}
+
+// out[c] (+)= sum_i in[i][c]: one thread per column walks the rows in order (B is a few thousand)
+__global__ __launch_bounds__(64) void col_sum_kernel(const float* __restrict__ in, int64_t B, int W, int accumulate,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= W) return;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int64_t r = 0;
+  for (; r + 4 <= B; r += 4) {
+    s0 += in[r * W + c];
+    s1 += in[(r + 1) * W + c];
+    s2 += in[(r + 2) * W + c];
+    s3 += in[(r + 3) * W + c];
+  }
+  for (; r < B; ++r) s0 += in[r * W + c];
+  const float t = (s0 + s1) + (s2 + s3);
+  out[c] = accumulate ? out[c] + t : t;
+}
+
+// dst[i] += src[i]
+__global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                       int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+
+inline unsigned blocks_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+struct Shape {
+  int64_t B;
+  int32_t L;
+  int32_t w[kMaxHidden + 1];  // w[0] = input width, w[l] = width of hidden layer l
+  int64_t h_off[kMaxHidden + 2];  // float offsets of h_1..h_L in `saved`
+  int64_t g_off[kMaxHidden + 2];  // float offsets of G_1..G_L
+  int64_t g0_off;
+  int64_t total_plain, total_r1;
+  int32_t max_w;
+};
+
+int make_shape(const char* what, int64_t B, int32_t layers, const int32_t* widths, Shape& s) {
+  HIVT_REQUIRE(B >= 0 && B < ((int64_t)1 << 31), HIVT_ERR_ARG, "%s: bad batch size", what);
+  HIVT_REQUIRE(layers >= 1 && layers <= kMaxHidden && widths != nullptr, HIVT_ERR_ARG,
+               "%s: %d hidden layers (1..%d)", what, layers, kMaxHidden);
+  s.B = B;
+  s.L = layers;
+  s.max_w = 0;
+  int64_t off = 0;
+  for (int l = 0; l <= layers; ++l) {
+    HIVT_REQUIRE(widths[l] >= 1 && widths[l] <= 4096, HIVT_ERR_ARG, "%s: layer width %d", what, widths[l]);
+    s.w[l] = widths[l];
+    if (widths[l] > s.max_w) s.max_w = widths[l];
+  }
+  for (int l = 1; l <= layers; ++l) {
+    s.h_off[l] = off;
+    off += align_up((size_t)(B * s.w[l]), 64);
+  }
+  s.total_plain = off;
+  for (int l = 1; l <= layers; ++l) {
+    s.g_off[l] = off;
+    off += align_up((size_t)(B * s.w[l]), 64);
+  }
+  s.g0_off = off;
+  off += align_up((size_t)(B * s.w[0]), 64);
+  s.total_r1 = off;
+  return HIVT_OK;
+}
+
+// scratch: two [B, max_w] activations + the largest weight-gradient workspace + one weight-sized buffer
+struct Scratch {
+  float* a;
+  float* b;
+  float* wtmp;
+  void* wgrad_ws;
+  size_t wgrad_bytes;
+};
+
+size_t scratch_bytes(const Shape& s) {
+  size_t act = align_up((size_t)(s.B > 0 ? s.B : 1) * s.max_w * sizeof(float), 256);
+  size_t wg = 0, wt = 0;
+  for (int l = 1; l <= s.L; ++l) {
+    const size_t q = hivt_linear_wgrad_workspace_bytes(s.B, s.w[l], s.w[l - 1]);
+    if (q > wg) wg = q;
+    const size_t t = align_up((size_t)s.w[l] * s.w[l - 1] * sizeof(float), 256);
+    if (t > wt) wt = t;
+  }
+  const size_t q = hivt_linear_wgrad_workspace_bytes(s.B, 1, s.w[s.L]);
+  if (q > wg) wg = q;
+  return 2 * act + wt + wg;
+}
+
+Scratch carve(const Shape& s, void* ws) {
+  Scratch k;
+  const size_t act = align_up((size_t)(s.B > 0 ? s.B : 1) * s.max_w * sizeof(float), 256);
+  size_t wt = 0;
+  for (int l = 1; l <= s.L; ++l) {
+    const size_t t = align_up((size_t)s.w[l] * s.w[l - 1] * sizeof(float), 256);
+    if (t > wt) wt = t;
+  }
+  char* p = reinterpret_cast<char*>(ws);
+  k.a = reinterpret_cast<float*>(p);
+  k.b = reinterpret_cast<float*>(p + act);
+  k.wtmp = reinterpret_cast<float*>(p + 2 * act);
+  k.wgrad_ws = p + 2 * act + wt;
+  k.wgrad_bytes = scratch_bytes(s) - 2 * act - wt;
+  return k;
+}
+
+#define HIVT_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != HIVT_OK) return rc__; \
+  } while (0)
+
+}  // namespace
+}  // namespace hivt
+
+using namespace hivt;
+
+extern "C" size_t hivt_critic_saved_floats(int64_t B, int32_t layers, const int32_t* widths, int32_t with_input_grad) {
+  Shape s;
+  if (make_shape("hivt_critic_saved_floats", B, layers, widths, s) != HIVT_OK) return 0;
+  const int64_t n = with_input_grad ? s.total_r1 : s.total_plain;
+  return (size_t)(n > 0 ? n : 1);
+}
+
+extern "C" size_t hivt_critic_workspace_bytes(int64_t B, int32_t layers, const int32_t* widths) {
+  Shape s;
+  if (make_shape("hivt_critic_workspace_bytes", B, layers, widths, s) != HIVT_OK) return 0;
+  return scratch_bytes(s);
+}
+
+extern "C" int hivt_critic_fwd(const float* x, int64_t x_ld, int64_t B, int32_t layers, const int32_t* widths,
+                               const float* const* w, const float* const* bias, float neg_slope, float dropout_p,
+                               uint64_t seed, const uint64_t* seed_ptr, int32_t with_input_grad, float* saved,
+                               float* scores, float* grad_norm2, hivt_stream_t stream) {
+  const char* what = "hivt_critic_fwd";
+  Shape s;
+  HIVT_TRY(make_shape(what, B, layers, widths, s));
+  HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  if (B == 0) return HIVT_OK;
+  HIVT_REQUIRE(x && w && bias && saved && scores, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(!with_input_grad || grad_norm2, HIVT_ERR_ARG, "%s: grad_norm2 is null", what);
+  HIVT_REQUIRE(x_ld >= s.w[0], HIVT_ERR_ARG, "%s: x_ld smaller than the input width", what);
+  for (int l = 0; l <= layers; ++l)
+    HIVT_REQUIRE(w[l] && bias[l], HIVT_ERR_ARG, "%s: null parameter (layer %d)", what, l);
+  hipStream_t st = (hipStream_t)stream;
+  const float keep_scale = 1.0f / (1.0f - dropout_p);
+  // hidden layers (every layer draws its own dropout stream)
+  const float* in = x;
+  int64_t in_ld = x_ld;
+  for (int l = 1; l <= layers; ++l) {
+    float* h = saved + s.h_off[l];
+    HIVT_TRY(hivt_linear_fwd(in, in_ld, w[l - 1], s.w[l - 1], bias[l - 1], nullptr, 0, nullptr, 0, nullptr, nullptr,
+                             0.0f, 0 /* plain */, neg_slope, dropout_p, seed + 0x51ED27ull * (uint64_t)l, seed_ptr,
+                             nullptr, 0, B, s.w[l], s.w[l - 1], h, s.w[l], nullptr, 0, nullptr, stream));
+    in = h;
+    in_ld = s.w[l];
+  }
+  // output layer: one column
+  HIVT_TRY(hivt_linear_fwd(in, in_ld, w[layers], s.w[layers], bias[layers], nullptr, 0, nullptr, 0, nullptr, nullptr,
+                           0.0f, 0, 1.0f, 0.0f, 0, nullptr, nullptr, 0, B, 1, s.w[layers], scores, 1, nullptr, 0,
+                           nullptr, stream));
+  if (!with_input_grad) return HIVT_OK;
+  // input-gradient chain
+  float* G = saved + s.g_off[layers];
+  hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[layers])), dim3(256), 0, st, (const float*)nullptr,
+                     (const float*)nullptr, w[layers], saved + s.h_off[layers], keep_scale, neg_slope, B, s.w[layers],
+                     G);
+  HIVT_CHECK_LAUNCH(what);
+  for (int l = layers; l >= 1; --l) {
+    float* g_prev = l > 1 ? saved + s.g_off[l - 1] : saved + s.g0_off;
+    HIVT_TRY(hivt_linear_bwd_data(saved + s.g_off[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], g_prev,
+                                  s.w[l - 1], stream));
+    if (l > 1) {
+      hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,
+                         (const float*)g_prev, (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l - 1],
+                         keep_scale, neg_slope, B, s.w[l - 1], g_prev);
+      HIVT_CHECK_LAUNCH(what);
+    }
+  }
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)((B + 3) / 4 > 2048 ? 2048 : (B + 3) / 4)), dim3(256), 0, st,
+                     (const float*)(saved + s.g0_off), B, s.w[0], grad_norm2);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x, int64_t x_ld, int64_t B,
+                               int32_t layers, const int32_t* widths, const float* const* w, float neg_slope,
+                               float dropout_p, const float* saved, float* const* dw, float* const* dbias, float* dx,
+                               void* workspace, size_t workspace_bytes, hivt_stream_t stream) {
+  const char* what = "hivt_critic_bwd";
+  Shape s;
+  HIVT_TRY(make_shape(what, B, layers, widths, s));
+  HIVT_REQUIRE(dw && dbias, HIVT_ERR_ARG, "%s: null gradient arrays", what);
+  for (int l = 0; l <= layers; ++l) HIVT_REQUIRE(dw[l] && dbias[l], HIVT_ERR_ARG, "%s: null gradient (layer %d)", what, l);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0 || (g_scores == nullptr && g_norm2 == nullptr)) {
+    for (int l = 1; l <= layers; ++l) {
+      zero_words(dw[l - 1], (int64_t)s.w[l] * s.w[l - 1], st);
+      zero_words(dbias[l - 1], s.w[l], st);
+    }
+    zero_words(dw[layers], s.w[layers], st);
+    zero_words(dbias[layers], 1, st);
+    if (dx != nullptr && B > 0) zero_words(dx, B * s.w[0], st);
+    HIVT_CHECK_LAUNCH(what);
+    return HIVT_OK;
+  }
+  HIVT_REQUIRE(x && w && saved, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace && workspace_bytes >= scratch_bytes(s), HIVT_ERR_WORKSPACE, "%s: workspace too small", what);
+  for (int l = 0; l <= layers; ++l) HIVT_REQUIRE(w[l], HIVT_ERR_ARG, "%s: null weight (layer %d)", what, l);
+  const Scratch k = carve(s, workspace);
+  const float keep_scale = 1.0f / (1.0f - dropout_p);
+
+  if (g_scores != nullptr) {
+    // ---- gradient of the scores: ordinary backward through the layers ----
+    // output layer: dw_o = g^T h_L, db_o = sum g
+    HIVT_TRY(hivt_linear_wgrad(g_scores, 1, saved + s.h_off[layers], s.w[layers], B, 1, s.w[layers], dw[layers],
+                               dbias[layers], k.wgrad_ws, k.wgrad_bytes, stream));
+    // dz_L = (g w_o) * c_L
+    float* dz = k.a;
+    float* other = k.b;
+    hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[layers])), dim3(256), 0, st, (const float*)nullptr,
+                       g_scores, w[layers], saved + s.h_off[layers], keep_scale, neg_slope, B, s.w[layers], dz);
+    HIVT_CHECK_LAUNCH(what);
+    for (int l = layers; l >= 1; --l) {
+      const float* h_prev = l > 1 ? saved + s.h_off[l - 1] : x;
+      const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : x_ld;
+      HIVT_TRY(hivt_linear_wgrad(dz, s.w[l], h_prev, h_prev_ld, B, s.w[l], s.w[l - 1], dw[l - 1], dbias[l - 1],
+                                 k.wgrad_ws, k.wgrad_bytes, stream));
+      if (l > 1 || dx != nullptr) {
+        float* dh = (l == 1) ? dx : other;
+        HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], dh, s.w[l - 1], stream));
+        if (l > 1) {
+          hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,
+                             (const float*)dh, (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l - 1],
+                             keep_scale, neg_slope, B, s.w[l - 1], dh);
+          HIVT_CHECK_LAUNCH(what);
+          float* t = dz;
+          dz = dh;
+          other = t;
+        }
+      }
+    }
+  } else {
+    for (int l = 1; l <= layers; ++l) zero_words(dbias[l - 1], s.w[l], st);
+    zero_words(dbias[layers], 1, st);
+    if (dx != nullptr) zero_words(dx, B * s.w[0], st);
+    HIVT_CHECK_LAUNCH(what);
+  }
+
+  if (g_norm2 != nullptr) {
+    // ---- gradient of ||dD/dx||^2: the second chain (weights only; the factors c_l are constants) ----
+    const bool accumulate = g_scores != nullptr;
+    float* e = k.a;
+    float* t = k.b;
+    hipLaunchKernelGGL(row_scale_kernel, dim3(blocks_for(B * s.w[0])), dim3(256), 0, st,
+                       (const float*)(saved + s.g0_off), g_norm2, 2.0f, B, s.w[0], e);
+    HIVT_CHECK_LAUNCH(what);
+    for (int l = 1; l <= layers; ++l) {
+      // dW_l (+)= G_l^T e_{l-1}
+      float* target = accumulate ? k.wtmp : dw[l - 1];
+      HIVT_TRY(hivt_linear_wgrad(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], target, nullptr,
+                                 k.wgrad_ws, k.wgrad_bytes, stream));
+      if (accumulate) {
+        const int64_t n = (int64_t)s.w[l] * s.w[l - 1];
+        hipLaunchKernelGGL(add_into_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dw[l - 1], (const float*)k.wtmp, n);
+        HIVT_CHECK_LAUNCH(what);
+      }
+      // e_l = (e_{l-1} W_l^T) * c_l
+      HIVT_TRY(hivt_linear_fwd(e, s.w[l - 1], w[l - 1], s.w[l - 1], nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                               0.0f, 0, 1.0f, 0.0f, 0, nullptr, nullptr, 0, B, s.w[l], s.w[l - 1], t, s.w[l], nullptr,
+                               0, nullptr, stream));
+      hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l])), dim3(256), 0, st, (const float*)t,
+                         (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l], keep_scale, neg_slope, B,
+                         s.w[l], t);
+      HIVT_CHECK_LAUNCH(what);
+      float* sw = e;
+      e = t;
+      t = sw;
+    }
+    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((s.w[layers] + 63) / 64)), dim3(64), 0, st, (const float*)e, B,
+                       s.w[layers], accumulate ? 1 : 0, dw[layers]);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  return HIVT_OK;
+}

@@ -120,13 +120,14 @@ struct Stage {
 };
 
 // What the direct epilogue applies to an accumulator element before it is stored:
-//   out = residual + dropout([relu](acc + bias[col] + add[row or add_index[row]][col]))
+//   out = residual + dropout([relu | leaky_relu](acc + bias[col] + add[row or add_index[row]][col]))
 struct Tail {
   const float* bias = nullptr;
   const float* add = nullptr;
   int64_t add_ld = 0;
   const int32_t* add_index = nullptr;  // optional: row gr adds add[add_index[gr]] (rows of a small table)
   int32_t add_rows = 0;                // rows of that table; indices are clamped into it
+  float neg_slope = 1.0f;              // LeakyReLU slope for negative values (1 = identity), applied before dropout
   float drop_p = 0.0f;                 // dropout probability; the mask is uniform01(seed, row * cols + col) >= p
   uint64_t seed = 0;
   const uint64_t* seed_ptr = nullptr;  // optional device-side value added to seed
@@ -243,6 +244,9 @@ struct Core {
         if (RELU) {
           v0 = fmaxf(v0, 0.0f);
           v1 = fmaxf(v1, 0.0f);
+        } else if (t.neg_slope != 1.0f) {
+          v0 = v0 > 0.0f ? v0 : v0 * t.neg_slope;
+          v1 = v1 > 0.0f ? v1 : v1 * t.neg_slope;
         }
         if (drop) {
           const uint64_t base = (uint64_t)gr * (uint64_t)cols;
@@ -763,8 +767,9 @@ using namespace hivt;
 extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
                                const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
                                const float* gamma, const float* beta, float eps,
-                               int epilogue, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
-                               const float* residual, int64_t res_ld, int64_t M, int32_t N, int32_t K, float* y,
+                               int epilogue, float neg_slope, float dropout_p, uint64_t seed,
+                               const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N,
+                               int32_t K, float* y,
                                int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream) {
   const char* what = "hivt_linear_fwd";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
@@ -784,6 +789,9 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
   HIVT_REQUIRE(!ln || (dropout_p == 0.0f && residual == nullptr), HIVT_ERR_UNSUPPORTED,
                "%s: dropout / residual are not built for the LayerNorm epilogues", what);
   a.t.bias = bias; a.t.add = add; a.t.add_ld = add_ld; a.t.add_index = add_index; a.t.add_rows = add_rows;
+  HIVT_REQUIRE(neg_slope == 1.0f || epilogue == EPI_NONE, HIVT_ERR_UNSUPPORTED,
+               "%s: a LeakyReLU slope goes with the plain epilogue only", what);
+  a.t.neg_slope = neg_slope;
   a.t.drop_p = dropout_p; a.t.seed = seed; a.t.seed_ptr = seed_ptr; a.t.residual = residual; a.t.res_ld = res_ld;
   a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;

@@ -86,11 +86,11 @@ class AdversarialDiscriminatorLoss(nn.Module):
         cnt = w.sum().clamp(min=1.0)
         total, logs = 0.0, {}
         for name, critic in critics.items():
-            r = real.detach().clone().requires_grad_(True)
-            d_real, d_fake = critic(r), critic(fake.detach())
-            (grad,) = torch.autograd.grad(outputs=d_real.sum(), inputs=r, create_graph=True, retain_graph=True,
-                                          only_inputs=True)
-            r1 = (grad.pow(2).reshape(grad.size(0), -1).sum(dim=1) * w).sum() / cnt
+            # score and ||d score / d input||^2 of the real samples come from ONE critic call, as in the
+            # reference (hinge and R1 share the forward pass, models/hivt.py:244-252)
+            d_real, grad_norm2 = critic.scores_and_input_grad_norm(real.detach())
+            d_fake = critic(fake.detach())
+            r1 = (grad_norm2 * w).sum() / cnt
             loss = (F.relu(1.0 - d_real) * w).sum() / cnt + (F.relu(1.0 + d_fake) * w).sum() / cnt + self.lambda_r1 * r1
             total = total + loss
             logs[f"d_loss_{name}"] = loss.detach()

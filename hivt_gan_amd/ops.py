@@ -504,7 +504,7 @@ class _FusedLinear(torch.autograd.Function):
         bias_c = bias.contiguous() if bias is not None else None
         _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w2), w2.stride(0), _p(bias_c), _p(add2),
                   add2.stride(0) if add2 is not None else 0, _p(add_index),
-                  add2.shape[0] if add_index is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi,
+                  add2.shape[0] if add_index is not None else 0, _p(gamma_c), _p(beta_c), float(eps), epi, 1.0,
                   float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(res2), res2.stride(0) if res2 is not None else 0,
                   m, n, k, _p(y), n, _p(z), n, _p(stats), _stream(x))
         need_y = relu and not ln  # the ReLU (and, with it, the dropout) mask is read off the output
@@ -831,3 +831,79 @@ def embed2(f: torch.Tensor, branch_params, eps: float) -> torch.Tensor:
     if f.shape[-1] < 2 * len(branch_params):
         raise ValueError("input rows are narrower than two components per branch")
     return _Embed2.apply(f, eps, *flat)
+
+
+# --------------------------------------------------------------------------------------------
+# A whole trajectory critic per call
+# --------------------------------------------------------------------------------------------
+class _Critic(torch.autograd.Function):
+    """``(scores [B], ||d score / d x||^2 [B] or None)`` of one critic MLP; forward and backward are one
+    library call each."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        neg_slope, dropout_p, seed, with_r1 = cfg
+        weights, biases = [p.contiguous() for p in params[0::2]], [p.contiguous() for p in params[1::2]]
+        _need_gpu(x, *weights)
+        layers = len(weights) - 1
+        x2 = x.reshape(x.shape[0], -1)
+        if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]) or x2.dtype != torch.float32:
+            x2 = x2.contiguous().float()
+        b = x2.shape[0]
+        widths_list = [x2.shape[1]] + [w.shape[0] for w in weights[:-1]]
+        for l, w in enumerate(weights[:-1]):
+            if w.shape[1] != widths_list[l]:
+                raise ValueError("critic layer widths do not chain")
+        if weights[-1].shape != (1, widths_list[-1]):
+            raise ValueError("the output layer must be [1, hidden]")
+        widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
+        dev = x2.device
+        saved = torch.empty(_lib.query("hivt_critic_saved_floats", b, layers, tuple(widths_list), int(with_r1)),
+                            dtype=torch.float32, device=dev)
+        scores = torch.empty(b, dtype=torch.float32, device=dev)
+        gn2 = torch.empty(b, dtype=torch.float32, device=dev) if with_r1 else None
+        _lib.call("hivt_critic_fwd", _p(x2), x2.stride(0) if b > 0 else widths_list[0], b, layers, widths,
+                  _ptr_array(weights), _ptr_array(biases), float(neg_slope), float(dropout_p), int(seed),
+                  _seed_ptr(dropout_p), int(with_r1), _p(saved), _p(scores), _p(gn2), _stream(x2))
+        ctx.save_for_backward(x2, saved, *weights)
+        ctx.cfg = (float(neg_slope), float(dropout_p), widths_list, tuple(x.shape), [tuple(t.shape) for t in biases])
+        ctx.set_materialize_grads(False)
+        if with_r1:
+            return scores, gn2
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_scores, g_norm2=None):
+        x2, saved, *weights = ctx.saved_tensors
+        neg_slope, dropout_p, widths_list, x_shape, bias_shapes = ctx.cfg
+        layers = len(weights) - 1
+        b = x2.shape[0]
+        dev = x2.device
+        widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
+        dws = [torch.empty_like(w) for w in weights]
+        dbs = [torch.empty(s, dtype=torch.float32, device=dev) for s in bias_shapes]
+        dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        ws = _workspace(_lib.query("hivt_critic_workspace_bytes", b, layers, tuple(widths_list)), dev)
+        gs = g_scores.contiguous() if g_scores is not None else None
+        gn = g_norm2.contiguous() if g_norm2 is not None else None
+        _lib.call("hivt_critic_bwd", _p(gs), _p(gn), _p(x2), x2.stride(0) if b > 0 else widths_list[0], b, layers, widths,
+                  _ptr_array(weights), neg_slope, dropout_p, _p(saved), _ptr_array(dws), _ptr_array(dbs), _p(dx),
+                  _p(ws), ws.numel(), _stream(x2))
+        grads = []
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return (dx.view(x_shape) if dx is not None else None, None, *grads)
+
+
+def critic_scores(x: torch.Tensor, weights, biases, neg_slope: float, dropout_p: float, training: bool,
+                  with_input_grad_norm: bool = False):
+    """Scores [B] of the critic MLP ``Linear -> LeakyReLU -> Dropout`` x L, then a one-wide Linear, over
+    ``x`` flattened to [B, -1]; with ``with_input_grad_norm`` also ``||d score_i / d x_i||^2`` [B] as a
+    differentiable quantity (what the R1 penalty averages)."""
+    if len(weights) != len(biases) or not 2 <= len(weights) <= 9:
+        raise ValueError("a critic has 1..8 hidden layers and an output layer")
+    p = float(dropout_p) if training else 0.0
+    params = [t for pair in zip(weights, biases) for t in pair]
+    cfg = (float(neg_slope), p, _fresh_seed() if p > 0.0 else 0, bool(with_input_grad_norm))
+    return _Critic.apply(x, cfg, *params)

@@ -209,6 +209,8 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
  * categorical lane embeddings enter (models/local_encoder.py:349-357).  Epilogues: none, ReLU,
  * LayerNorm(gamma, beta, eps) and LayerNorm + ReLU (N <= 128); the LayerNorm epilogues also write
  * the pre-normalisation values z (optional) and per-row (mean, rstd) into stats [M,2].
+ * The plain epilogue can apply a LeakyReLU (neg_slope != 1: negative values are multiplied by it; the
+ * critics' activation, models/critics/base_critic.py:28-31).
  * The plain epilogues (none, ReLU) can finish with y = residual + dropout(.) (dropout_p in [0,1), mask
  * from a counter-based generator keyed on (seed [+ *seed_ptr], row * N + col); residual [M,N] or NULL),
  * which is the "x + Dropout(Linear(.))" tail of every attention and feed-forward block
@@ -219,9 +221,10 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
  * (models/local_encoder.py:117-122). */
 int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
                     const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
-                    const float* gamma, const float* beta, float eps, int epilogue, float dropout_p, uint64_t seed,
-                    const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N, int32_t K,
-                    float* y, int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream);
+                    const float* gamma, const float* beta, float eps, int epilogue, float neg_slope, float dropout_p,
+                    uint64_t seed, const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M,
+                    int32_t N, int32_t K, float* y, int64_t y_ld, float* z, int64_t z_ld, float* stats,
+                    hivt_stream_t stream);
 
 /* Gradient through the dropout (and ReLU) of hivt_linear_fwd's plain epilogues:
  * dz = dy * keep / (1 - dropout_p) [* (y > 0) when relu != 0; y is then the forward output and the mask
@@ -367,6 +370,41 @@ int hivt_spectral_norm_fwd(int32_t layers, const float* const* w, float* const* 
 int hivt_spectral_norm_bwd(int32_t layers, const float* const* d_wn, const float* const* w,
                            const float* const* u_used, const float* const* v_used, const float* sigma,
                            const int32_t* rows, const int32_t* cols, float* const* d_w, hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A whole trajectory critic per call
+ * ------------------------------------------------------------------------------------------ */
+
+#define HIVT_CRITIC_MAX_LAYERS 8 /* hidden layers */
+
+/* A critic is the MLP of models/critics/base_critic.py:19-44 over B flattened trajectories:
+ *     h_l = Dropout(LeakyReLU_{neg_slope}(h_{l-1} W_l^T + b_l)), l = 1..layers;   score = h_L w_o^T + b_o.
+ * widths[0..layers] = input width, hidden widths.  w / bias are HOST arrays of layers+1 device pointers
+ * (W_l float [widths[l], widths[l-1]], then w_o float [1, widths[layers]]; b_l [widths[l]], b_o [1]) --
+ * the spectrally normalised weights of hivt_spectral_norm_fwd.
+ *
+ * hivt_critic_fwd writes scores float [B] and keeps the hidden activations in `saved`
+ * (hivt_critic_saved_floats floats).  With with_input_grad it also evaluates g = d score / d x per sample
+ * by the chain G_L = w_o * c_L, g_{l-1} = G_l W_l, G_{l-1} = g_{l-1} * c_{l-1} (c_l = the activation /
+ * dropout factor, read off the stored h_l) and writes grad_norm2[i] = ||g_i||^2 -- the quantity the R1
+ * penalty averages (losses/adv_losses.py:36-47, models/hivt.py:244-252) -- without a double backward.
+ * Dropout masks come from the counter-based generator keyed on (seed [+ *seed_ptr], layer, element). */
+size_t hivt_critic_saved_floats(int64_t B, int32_t layers, const int32_t* widths, int32_t with_input_grad);
+size_t hivt_critic_workspace_bytes(int64_t B, int32_t layers, const int32_t* widths);
+int hivt_critic_fwd(const float* x, int64_t x_ld, int64_t B, int32_t layers, const int32_t* widths,
+                    const float* const* w, const float* const* bias, float neg_slope, float dropout_p, uint64_t seed,
+                    const uint64_t* seed_ptr, int32_t with_input_grad, float* saved, float* scores,
+                    float* grad_norm2, hivt_stream_t stream);
+
+/* Gradients of a loss with d loss / d scores = g_scores [B] (or NULL) and d loss / d grad_norm2 = g_norm2
+ * [B] (or NULL) with respect to every weight (dw[l], same shapes as w[l]) and bias, and optionally the
+ * input (dx float [B, widths[0]] contiguous, from the score path only: the factors c_l are constants).
+ * The grad_norm2 path is the second chain e_0 = 2 g_norm2 g, dW_l += G_l^T e_{l-1},
+ * e_l = (e_{l-1} W_l^T) * c_l, dw_o += colsum(e_L). */
+int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x, int64_t x_ld, int64_t B,
+                    int32_t layers, const int32_t* widths, const float* const* w, float neg_slope, float dropout_p,
+                    const float* saved, float* const* dw, float* const* dbias, float* dx, void* workspace,
+                    size_t workspace_bytes, hivt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -324,9 +324,10 @@ def test_r1_double_backward_coexists_with_custom_functions():
 # Critics: fused spectral normalisation
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("training", [True, False])
-def test_critic_spectral_norm_kernel_matches_framework_hook(training):
-    """One launch per critic call against torch.nn.utils.spectral_norm layers holding the same state:
-    scores, the advanced u / v buffers, and the gradients (including R1's double backward)."""
+def test_critic_matches_framework_hook_layers(training):
+    """The critic (one spectral-norm launch + one MLP call per forward) against
+    torch.nn.utils.spectral_norm layers holding the same state: scores, the advanced u / v buffers, the
+    R1 quantity (double backward on the framework side) and every gradient."""
     import copy
     from torch.nn.utils import spectral_norm
 
@@ -335,7 +336,6 @@ def test_critic_spectral_norm_kernel_matches_framework_hook(training):
     for mod in critic.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    # the same network built from hooked framework layers
     ref_layers = []
     for m in critic._spectral_layers():
         lin = spectral_norm(torch.nn.Linear(m.in_features, m.out_features)).to(DEV)
@@ -352,15 +352,17 @@ def test_critic_spectral_norm_kernel_matches_framework_hook(training):
         return ref_layers[-1](h).squeeze(-1)
 
     x = torch.randn(300, 30, 2, device=DEV)
+    wts = torch.rand(300, device=DEV)
     for call in range(2):  # two calls: the second starts from the advanced vectors
-        xa = x.clone().requires_grad_(True)
+        sa, na = critic.scores_and_input_grad_norm(x)
         xb = x.clone().requires_grad_(True)
-        sa, sb = critic(xa), ref_forward(xb)
-        assert_close(sa, sb, 1e-5, msg=f"scores call {call}")
-        (ga,) = torch.autograd.grad(sa.sum(), xa, create_graph=True)
+        sb = ref_forward(xb)
         (gb,) = torch.autograd.grad(sb.sum(), xb, create_graph=True)
-        la = F.relu(1.0 - sa).mean() + ga.pow(2).sum(dim=(1, 2)).mean()
-        lb = F.relu(1.0 - sb).mean() + gb.pow(2).sum(dim=(1, 2)).mean()
+        nb = gb.pow(2).sum(dim=(1, 2))
+        assert_close(sa, sb, 1e-5, msg=f"scores call {call}")
+        assert_close(na, nb, 2e-5, msg=f"grad norm call {call}")
+        la = (F.relu(1.0 - sa) * wts).sum() + (na * wts).sum()
+        lb = (F.relu(1.0 - sb) * wts).sum() + (nb * wts).sum()
         for p in critic.parameters():
             p.grad = None
         for lin in ref_layers:
@@ -371,9 +373,84 @@ def test_critic_spectral_norm_kernel_matches_framework_hook(training):
         for m, lin in zip(critic._spectral_layers(), ref_layers):
             assert_close(m.weight_u, lin.weight_u, 1e-5, msg="u")
             assert_close(m.weight_v, lin.weight_v, 1e-5, msg="v")
-            assert_close(m.weight_orig.grad, lin.weight_orig.grad, 2e-5, msg="d weight_orig")
-            assert_close(m.bias.grad, lin.bias.grad, 2e-5, msg="d bias")
-        assert_close(xa.grad, xb.grad, 2e-5, msg="d input")
+            assert_close(m.weight_orig.grad, lin.weight_orig.grad, 3e-5, msg="d weight_orig")
+            assert_close(m.bias.grad, lin.bias.grad, 3e-5, msg="d bias")
+    # gradient with respect to the trajectories (the generator's adversarial term), evaluation mode
+    critic.eval()
+    for lin in ref_layers:
+        lin.eval()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    (ga,) = torch.autograd.grad((critic(xa) * wts).sum(), xa)
+    (gb,) = torch.autograd.grad((ref_forward(xb) * wts).sum(), xb)
+    assert_close(ga, gb, 2e-5, msg="d input")
+
+
+@pytest.mark.parametrize("B,widths,p", [(777, [60, 256, 256, 256, 256], 0.3), (1, [20, 128, 128], 0.0),
+                                        (2623, [40, 256, 256, 256], 0.1)])
+def test_critic_entry_points_with_dropout(B, widths, p):
+    """hivt_critic_fwd / hivt_critic_bwd through the C ABI, dropout on: the masks are read back from the
+    saved activations and replayed through framework ops, whose double backward is the reference for
+    the ||d score / d x||^2 path."""
+    import ctypes
+    from hivt_gan_amd import _lib
+    gen = torch.Generator().manual_seed(B + len(widths))
+    L = len(widths) - 1
+    x = torch.randn(B, widths[0], generator=gen).to(DEV)
+    ws = [(torch.randn(widths[l + 1], widths[l], generator=gen) / widths[l] ** 0.5).to(DEV) for l in range(L)]
+    ws.append((torch.randn(1, widths[L], generator=gen) / widths[L] ** 0.5).to(DEV))
+    bs = [(torch.randn(widths[l + 1], generator=gen) * 0.1).to(DEV) for l in range(L)] + [torch.randn(1, generator=gen).to(DEV)]
+    slope = 0.2
+    c_w = (ctypes.c_int32 * (L + 1))(*widths)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    n_saved = _lib.query("hivt_critic_saved_floats", B, L, tuple(widths), 1)
+    saved = torch.zeros(n_saved, device=DEV)
+    scores, gn2 = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.call("hivt_critic_fwd", x.data_ptr(), widths[0], B, L, c_w, arr(ws), arr(bs), slope, p, 1234, None, 1,
+              saved.data_ptr(), scores.data_ptr(), gn2.data_ptr(), stream)
+    # hidden activations are the first blocks of `saved` (each padded to 64 floats)
+    hs, off = [], 0
+    for l in range(1, L + 1):
+        hs.append(saved[off:off + B * widths[l]].view(B, widths[l]).clone())
+        off += (B * widths[l] + 63) // 64 * 64
+    # framework replay with the same masks
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    h = xr
+    for l in range(L):
+        # the activation / dropout factor of every element is taken from the library's own output (its
+        # sign), so that an element whose pre-activation is zero up to rounding sits on the same linear
+        # piece on both sides
+        factor = torch.where(hs[l] > 0, 1.0, slope) * (hs[l] != 0).float() / (1.0 - p)
+        if p > 0.0:
+            kept = float((hs[l] != 0).float().mean())
+            assert abs(kept - (1.0 - p)) < 0.02, (l, kept)
+        h = F.linear(h, wr[l], br[l]) * factor
+        assert_close(hs[l], h, 1e-5, msg=f"h{l + 1}")
+    sr = F.linear(h, wr[L], br[L]).squeeze(-1)
+    (gx,) = torch.autograd.grad(sr.sum(), xr, create_graph=True)
+    nr = gx.pow(2).sum(dim=1)
+    assert_close(scores, sr, 1e-5, msg="scores")
+    assert_close(gn2, nr, 3e-5, msg="grad norm")
+    g_s = torch.randn(B, generator=gen).to(DEV)
+    g_n = torch.randn(B, generator=gen).to(DEV)
+    dws = [torch.empty_like(w) for w in ws]
+    dbs = [torch.empty_like(b) for b in bs]
+    dx = torch.empty(B, widths[0], device=DEV)
+    wsb = torch.empty(_lib.query("hivt_critic_workspace_bytes", B, L, tuple(widths)), dtype=torch.uint8, device=DEV)
+    for use_s, use_n in ((True, True), (True, False), (False, True)):
+        _lib.call("hivt_critic_bwd", g_s.data_ptr() if use_s else None, g_n.data_ptr() if use_n else None, x.data_ptr(),
+                  widths[0], B, L, c_w, arr(ws), slope, p, saved.data_ptr(), arr(dws), arr(dbs), dx.data_ptr(),
+                  wsb.data_ptr(), wsb.numel(), stream)
+        loss = (sr * g_s).sum() * (1.0 if use_s else 0.0) + (nr * g_n).sum() * (1.0 if use_n else 0.0)
+        ref = torch.autograd.grad(loss, wr + br, retain_graph=True, allow_unused=True)
+        for l in range(L + 1):
+            assert_close(dws[l], ref[l], 5e-5, msg=f"dW{l} {use_s}{use_n}")
+            rb = ref[L + 1 + l] if ref[L + 1 + l] is not None else torch.zeros_like(bs[l])
+            assert_close(dbs[l], rb, 5e-5, msg=f"db{l} {use_s}{use_n}")
+        ref_dx = torch.autograd.grad((sr * g_s).sum(), xr, retain_graph=True)[0] if use_s else torch.zeros_like(x)
+        assert_close(dx, ref_dx, 5e-5, msg=f"dx {use_s}{use_n}")
 
 
 def test_temporal_last_position_equals_full_layer_row():
