@@ -69,24 +69,6 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
   }
 }
 
-// out[c] (+)= sum_i in[i][c]: one thread per column walks the rows in order (B is a few thousand)
-__global__ __launch_bounds__(64) void col_sum_kernel(const float* __restrict__ in, int64_t B, int W, int accumulate,
-                                                     float* __restrict__ out) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= W) return;
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int64_t r = 0;
-  for (; r + 4 <= B; r += 4) {
-    s0 += in[r * W + c];
-    s1 += in[(r + 1) * W + c];
-    s2 += in[(r + 2) * W + c];
-    s3 += in[(r + 3) * W + c];
-  }
-  for (; r < B; ++r) s0 += in[r * W + c];
-  const float t = (s0 + s1) + (s2 + s3);
-  out[c] = accumulate ? out[c] + t : t;
-}
-
 // dst[i] += src[i]
 __global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                        int64_t n) {
@@ -353,8 +335,15 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
       e = t;
       t = sw;
     }
-    hipLaunchKernelGGL(col_sum_kernel, dim3((unsigned)((s.w[layers] + 63) / 64)), dim3(64), 0, st, (const float*)e, B,
-                       s.w[layers], accumulate ? 1 : 0, dw[layers]);
+    // dw_o (+)= column sums of e_L (rows summed in a fixed order)
+    if (accumulate) {
+      reduce_partials(e, (int)B, s.w[layers], k.wtmp, st);
+      HIVT_CHECK_LAUNCH(what);
+      hipLaunchKernelGGL(add_into_kernel, dim3(blocks_for(s.w[layers])), dim3(256), 0, st, dw[layers],
+                         (const float*)k.wtmp, (int64_t)s.w[layers]);
+    } else {
+      reduce_partials(e, (int)B, s.w[layers], dw[layers], st);
+    }
     HIVT_CHECK_LAUNCH(what);
   }
   return HIVT_OK;

@@ -22,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
+constexpr unsigned kSmallGrid = 384;  // workgroups: up to 1.5 per compute unit
 
 enum Epilogue : int { EPI_NONE = 0, EPI_RELU = 1, EPI_LN = 2, EPI_LN_RELU = 3 };
 
@@ -135,7 +136,10 @@ struct Tail {
   int64_t res_ld = 0;
 };
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false>
+// DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
+// step s is multiplied (used for small grids, where no other workgroup shares the compute unit to
+// hide the load latency behind; it costs registers, hence occupancy, on large grids).
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false>
 struct Core {
   using SA = Stage<BM, TA, VEC, ACC_A>;
   using SB = Stage<BN, TB, VEC>;
@@ -162,43 +166,105 @@ struct Core {
       acc0[r] = 0.0f;
       acc1[r] = 0.0f;
     }
-    SA sa;
-    SB sb;
     // buffer b of operand A starts at b * BUF, of operand B at b * BUF + A_FLOATS (plain integer
     // offsets into the one __shared__ array, so every access stays an LDS instruction)
     constexpr int BUF = A_FLOATS + B_FLOATS;
     const int steps = (red_end - red_begin + kBK - 1) / kBK;
-    if (steps > 0) {
-      sa.load(a, row0, red_begin, tid);
-      sb.load(b, col0, red_begin, tid);
-      sa.store(lds, tid);
-      sb.store(lds + A_FLOATS, tid);
-    }
-    __syncthreads();
-    for (int s = 0; s < steps; ++s) {
-      const int cur = (s & 1) * BUF;
-      const int nxt = BUF - cur;
-      if (s + 1 < steps) {
-        sa.load(a, row0, red_begin + (s + 1) * kBK, tid);
-        sb.load(b, col0, red_begin + (s + 1) * kBK, tid);
-      }
+    // All operand reads of a step are issued before its first MFMA (two halves of 8 k-pairs), so the LDS
+    // latency is paid once per half instead of once per k-pair when a wave has its SIMD to itself.
+    auto multiply = [&](int cur) {
       const int ao = cur + wr * 32 + lo;
       const int bo = cur + A_FLOATS + wc * 64 + lo;
+      constexpr int HALF = kBK / 4;  // k-pairs per half
 #pragma unroll
-      for (int kk = 0; kk < kBK; kk += 2) {
-        const float av = lds[ao + (kk + hi) * SA::PITCH];
-        const float b0 = lds[bo + (kk + hi) * SB::PITCH];
-        const float b1 = lds[bo + (kk + hi) * SB::PITCH + 32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+      for (int half = 0; half < 2; ++half) {
+        float av[HALF], b0[HALF], b1[HALF];
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+          const int kk = (half * HALF + i) * 2;
+          av[i] = lds[ao + (kk + hi) * SA::PITCH];
+          b0[i] = lds[bo + (kk + hi) * SB::PITCH];
+          b1[i] = lds[bo + (kk + hi) * SB::PITCH + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs: the scheduler would sink them
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+        }
       }
-      if (s + 1 < steps) {
-        sa.store(lds + nxt, tid);
-        sb.store(lds + nxt + A_FLOATS, tid);
+    };
+    if constexpr (!DEEP) {
+      SA sa;
+      SB sb;
+      if (steps > 0) {
+        sa.load(a, row0, red_begin, tid);
+        sb.load(b, col0, red_begin, tid);
+        sa.store(lds, tid);
+        sb.store(lds + A_FLOATS, tid);
       }
       __syncthreads();
+      for (int s = 0; s < steps; ++s) {
+        const int cur = (s & 1) * BUF;
+        const int nxt = BUF - cur;
+        if (s + 1 < steps) {
+          sa.load(a, row0, red_begin + (s + 1) * kBK, tid);
+          sb.load(b, col0, red_begin + (s + 1) * kBK, tid);
+        }
+        multiply(cur);
+        if (s + 1 < steps) {
+          sa.store(lds + nxt, tid);
+          sb.store(lds + nxt + A_FLOATS, tid);
+        }
+        __syncthreads();
+      }
+      if (ACC_A) *a_colsum = sa.colsum;
+    } else {
+      SA sa[2];
+      SB sb[2];
+      if (steps > 0) {
+        sa[0].load(a, row0, red_begin, tid);
+        sb[0].load(b, col0, red_begin, tid);
+      }
+      if (steps > 1) {
+        sa[1].load(a, row0, red_begin + kBK, tid);
+        sb[1].load(b, col0, red_begin + kBK, tid);
+      }
+      if (steps > 0) {
+        sa[0].store(lds, tid);
+        sb[0].store(lds + A_FLOATS, tid);
+      }
+      __syncthreads();
+      for (int s = 0; s < steps; s += 2) {
+        // even step: multiply buffer 0, fetch step s + 2 into set 0, publish set 1 (step s + 1) in buffer 1
+        if (s + 2 < steps) {
+          sa[0].load(a, row0, red_begin + (s + 2) * kBK, tid);
+          sb[0].load(b, col0, red_begin + (s + 2) * kBK, tid);
+        }
+        multiply(0);
+        if (s + 1 < steps) {
+          sa[1].store(lds + BUF, tid);
+          sb[1].store(lds + BUF + A_FLOATS, tid);
+        }
+        __syncthreads();
+        if (s + 1 >= steps) break;
+        // odd step: multiply buffer 1, fetch step s + 3 into set 1, publish set 0 (step s + 2) in buffer 0
+        if (s + 3 < steps) {
+          sa[1].load(a, row0, red_begin + (s + 3) * kBK, tid);
+          sb[1].load(b, col0, red_begin + (s + 3) * kBK, tid);
+        }
+        multiply(BUF);
+        if (s + 2 < steps) {
+          sa[0].store(lds, tid);
+          sb[0].store(lds + A_FLOATS, tid);
+        }
+        __syncthreads();
+      }
+      if (ACC_A) {
+        const float4 c0 = sa[0].colsum, c1 = sa[1].colsum;
+        *a_colsum = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
+      }
     }
-    if (ACC_A) *a_colsum = sa.colsum;
   }
 
   // accumulators -> LDS tile C[row][col] (pitch C_PITCH); the staging buffers are dead after the last
@@ -281,9 +347,9 @@ struct FwdArgs {
   int32_t M, N;
 };
 
-template <int BM, int BN, int EPI, bool VEC>
+template <int BM, int BN, int EPI, bool VEC, bool DEEP = false>
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
-  using C = Core<BM, BN, true, true, VEC>;
+  using C = Core<BM, BN, true, true, VEC, false, DEEP>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   Operand xa = a.x, wa = a.w;
@@ -378,9 +444,9 @@ struct BwdDataArgs {
   int32_t M, K;
 };
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool DEEP = false>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
-  using C = Core<BM, BN, true, false, VEC>;
+  using C = Core<BM, BN, true, false, VEC, false, DEEP>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
@@ -399,9 +465,9 @@ struct WgradArgs {
   int32_t N, K, M, chunk_rows;
 };
 
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, bool DEEP = false>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
-  using C = Core<BM, BN, false, false, VEC, true>;
+  using C = Core<BM, BN, false, false, VEC, true, DEEP>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   __shared__ float bsum[kThreads / (BM / 4)][BM];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
@@ -797,8 +863,11 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
+  // grids that leave compute units with a single workgroup get the deep-prefetch variant
 #define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
-  if (vec)                                                                                                   \
+  if (vec && grid.x * grid.y <= kSmallGrid)                                                                  \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true>), grid, dim3(kThreads), 0, s, a);        \
+  else if (vec)                                                                                              \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true>), grid, dim3(kThreads), 0, s, a);              \
   else                                                                                                       \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, false>), grid, dim3(kThreads), 0, s, a);             \
@@ -839,13 +908,17 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
   if (K <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), 1);
-    if (vec)
+    if (vec && grid.x <= kSmallGrid)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec)
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true>), grid, dim3(kThreads), 0, s, a);
     else
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, false>), grid, dim3(kThreads), 0, s, a);
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 127) / 128));
-    if (vec)
+    if (vec && grid.x * grid.y <= kSmallGrid)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec)
       hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);
     else
       hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, false>), grid, dim3(kThreads), 0, s, a);
@@ -888,7 +961,9 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   a.bias_partial = dbias ? a.partial + (size_t)N * K : nullptr;
   a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
-  if (a.dy.vec_ok && a.x.vec_ok)
+  if (a.dy.vec_ok && a.x.vec_ok && grid.x * grid.y * grid.z <= kSmallGrid)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
+  else if (a.dy.vec_ok && a.x.vec_ok)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);
   else
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, false>), grid, dim3(kThreads), 0, s, a);
