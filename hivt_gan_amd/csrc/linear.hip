@@ -26,6 +26,19 @@ constexpr unsigned kSmallGrid = 384;  // workgroups: up to 1.5 per compute unit
 
 enum Epilogue : int { EPI_NONE = 0, EPI_RELU = 1, EPI_LN = 2, EPI_LN_RELU = 3 };
 
+// Timeline probe for kernel tuning (tools/probe_linear.py builds a private copy of this file with
+// -DHIVT_PROBE); the shipped library compiles the stamps away.
+#ifdef HIVT_PROBE
+__device__ long long* d_probe = nullptr;
+#define HIVT_STAMP(i)                                                                                   \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && d_probe != nullptr)                                                         \
+      d_probe[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)wall_clock64();     \
+  } while (0)
+#else
+#define HIVT_STAMP(i) do { } while (0)
+#endif
+
 // Operand descriptor: logical matrix Op[row][red] (row = output index, red = reduction index).
 // TRANS = true : memory is [row][red] (contiguous along the reduction)  -> transposing stage
 // TRANS = false: memory is [red][row] (contiguous along the output row) -> straight copy
@@ -88,35 +101,38 @@ struct Stage {
     }
   }
 
+  // One float4 of the staged step (r < NVEC) goes to LDS; store() sends all of them.
+  __device__ __forceinline__ void store_piece(float* lds, int tid, int r) {
+    const int idx = tid + r * kThreads;
+    const unsigned m = ok >> (4 * r);
+    float4 val;
+    val.x = (m & 1u) ? v[r].x : 0.0f;
+    val.y = (m & 2u) ? v[r].y : 0.0f;
+    val.z = (m & 4u) ? v[r].z : 0.0f;
+    val.w = (m & 8u) ? v[r].w : 0.0f;
+    if (ACCUM) {
+      colsum.x += val.x;
+      colsum.y += val.y;
+      colsum.z += val.z;
+      colsum.w += val.w;
+    }
+    if (TRANS) {
+      const int row = idx / (kBK / 4);
+      const int red = (idx % (kBK / 4)) * 4;
+      lds[(red + 0) * PITCH + row] = val.x;
+      lds[(red + 1) * PITCH + row] = val.y;
+      lds[(red + 2) * PITCH + row] = val.z;
+      lds[(red + 3) * PITCH + row] = val.w;
+    } else {
+      const int red = idx / (ROWS / 4);
+      const int row = (idx % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(lds + red * PITCH + row) = val;
+    }
+  }
+
   __device__ __forceinline__ void store(float* lds, int tid) {
 #pragma unroll
-    for (int r = 0; r < NVEC; ++r) {
-      const int idx = tid + r * kThreads;
-      const unsigned m = ok >> (4 * r);
-      float4 val;
-      val.x = (m & 1u) ? v[r].x : 0.0f;
-      val.y = (m & 2u) ? v[r].y : 0.0f;
-      val.z = (m & 4u) ? v[r].z : 0.0f;
-      val.w = (m & 8u) ? v[r].w : 0.0f;
-      if (ACCUM) {
-        colsum.x += val.x;
-        colsum.y += val.y;
-        colsum.z += val.z;
-        colsum.w += val.w;
-      }
-      if (TRANS) {
-        const int row = idx / (kBK / 4);
-        const int red = (idx % (kBK / 4)) * 4;
-        lds[(red + 0) * PITCH + row] = val.x;
-        lds[(red + 1) * PITCH + row] = val.y;
-        lds[(red + 2) * PITCH + row] = val.z;
-        lds[(red + 3) * PITCH + row] = val.w;
-      } else {
-        const int red = idx / (ROWS / 4);
-        const int row = (idx % (ROWS / 4)) * 4;
-        *reinterpret_cast<float4*>(lds + red * PITCH + row) = val;
-      }
-    }
+    for (int r = 0; r < NVEC; ++r) store_piece(lds, tid, r);
   }
 };
 
@@ -150,6 +166,7 @@ struct Core {
   static constexpr int C_FLOATS = BM * C_PITCH;
   static constexpr int LDS_FLOATS = STAGE_FLOATS > C_FLOATS ? STAGE_FLOATS : C_FLOATS;
   static constexpr int WN = BN / 64;  // waves along the columns; each wave owns 32 x 64
+  static_assert(SA::NVEC + SB::NVEC <= kBK / 4, "one staged float4 per second k-pair must cover a step");
 
   // Accumulates the product over [red_begin, red_end) into the calling wave's two 32x32 accumulators
   // (rows wr*32.., columns wc*64.. and wc*64+32..).  All threads of the block must call it.
@@ -172,7 +189,9 @@ struct Core {
     const int steps = (red_end - red_begin + kBK - 1) / kBK;
     // All operand reads of a step are issued before its first MFMA (two halves of 8 k-pairs), so the LDS
     // latency is paid once per half instead of once per k-pair when a wave has its SIMD to itself.
-    auto multiply = [&](int cur) {
+    // between(kp) runs after the MFMAs of k-pair kp (0..15): work placed there is issued while the
+    // matrix unit is busy.
+    auto multiply = [&](int cur, auto&& between) {
       const int ao = cur + wr * 32 + lo;
       const int bo = cur + A_FLOATS + wc * 64 + lo;
       constexpr int HALF = kBK / 4;  // k-pairs per half
@@ -191,8 +210,22 @@ struct Core {
         for (int i = 0; i < HALF; ++i) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0[i], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1[i], acc1, 0, 0, 0);
+          between(half * HALF + i);
         }
       }
+    };
+    auto nothing = [](int) {};
+    // Publishes a staged register set in LDS piecewise from inside multiply(): one float4 after every
+    // second k-pair, all of them out by k-pair 11 of 16.
+    auto publish = [&](SA& pa, SB& pb, int dst) {
+      return [&pa, &pb, dst, lds, tid](int kp) {
+        const int piece = kp >> 1;
+        if ((kp & 1) == 0 || piece >= SA::NVEC + SB::NVEC) return;
+        if (piece < SA::NVEC)
+          pa.store_piece(lds + dst, tid, piece);
+        else
+          pb.store_piece(lds + dst + A_FLOATS, tid, piece - SA::NVEC);
+      };
     };
     if constexpr (!DEEP) {
       SA sa;
@@ -204,6 +237,7 @@ struct Core {
         sb.store(lds + A_FLOATS, tid);
       }
       __syncthreads();
+      HIVT_STAMP(1);
       for (int s = 0; s < steps; ++s) {
         const int cur = (s & 1) * BUF;
         const int nxt = BUF - cur;
@@ -211,7 +245,7 @@ struct Core {
           sa.load(a, row0, red_begin + (s + 1) * kBK, tid);
           sb.load(b, col0, red_begin + (s + 1) * kBK, tid);
         }
-        multiply(cur);
+        multiply(cur, nothing);
         if (s + 1 < steps) {
           sa.store(lds + nxt, tid);
           sb.store(lds + nxt + A_FLOATS, tid);
@@ -220,44 +254,30 @@ struct Core {
       }
       if (ACC_A) *a_colsum = sa.colsum;
     } else {
+      // Every load and every LDS store below is unconditional: loads past the end of the reduction
+      // range are clamped in bounds and masked to zero (Stage::load), and an odd step count is padded
+      // by one all-zero step.  Straight-line code lets the compiler count the loads in flight, so
+      // waiting for one register set leaves the other set's loads outstanding.
       SA sa[2];
       SB sb[2];
-      if (steps > 0) {
-        sa[0].load(a, row0, red_begin, tid);
-        sb[0].load(b, col0, red_begin, tid);
-      }
-      if (steps > 1) {
-        sa[1].load(a, row0, red_begin + kBK, tid);
-        sb[1].load(b, col0, red_begin + kBK, tid);
-      }
-      if (steps > 0) {
-        sa[0].store(lds, tid);
-        sb[0].store(lds + A_FLOATS, tid);
-      }
+      sa[0].load(a, row0, red_begin, tid);
+      sb[0].load(b, col0, red_begin, tid);
+      sa[1].load(a, row0, red_begin + kBK, tid);
+      sb[1].load(b, col0, red_begin + kBK, tid);
+      sa[0].store(lds, tid);
+      sb[0].store(lds + A_FLOATS, tid);
       __syncthreads();
+      HIVT_STAMP(1);
       for (int s = 0; s < steps; s += 2) {
         // even step: multiply buffer 0, fetch step s + 2 into set 0, publish set 1 (step s + 1) in buffer 1
-        if (s + 2 < steps) {
-          sa[0].load(a, row0, red_begin + (s + 2) * kBK, tid);
-          sb[0].load(b, col0, red_begin + (s + 2) * kBK, tid);
-        }
-        multiply(0);
-        if (s + 1 < steps) {
-          sa[1].store(lds + BUF, tid);
-          sb[1].store(lds + BUF + A_FLOATS, tid);
-        }
+        sa[0].load(a, row0, red_begin + (s + 2) * kBK, tid);
+        sb[0].load(b, col0, red_begin + (s + 2) * kBK, tid);
+        multiply(0, publish(sa[1], sb[1], BUF));
         __syncthreads();
-        if (s + 1 >= steps) break;
         // odd step: multiply buffer 1, fetch step s + 3 into set 1, publish set 0 (step s + 2) in buffer 0
-        if (s + 3 < steps) {
-          sa[1].load(a, row0, red_begin + (s + 3) * kBK, tid);
-          sb[1].load(b, col0, red_begin + (s + 3) * kBK, tid);
-        }
-        multiply(BUF);
-        if (s + 2 < steps) {
-          sa[0].store(lds, tid);
-          sb[0].store(lds + A_FLOATS, tid);
-        }
+        sa[1].load(a, row0, red_begin + (s + 3) * kBK, tid);
+        sb[1].load(b, col0, red_begin + (s + 3) * kBK, tid);
+        multiply(BUF, publish(sa[0], sb[0], 0));
         __syncthreads();
       }
       if (ACC_A) {
@@ -282,30 +302,67 @@ struct Core {
     __syncthreads();
   }
 
+  // Bias values of the two columns a lane owns; loaded before the reduction loop so that the
+  // latency is not paid in the epilogue.
+  __device__ static float2 bias_pair(const Tail& t, int col0, int cols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = col0 + (wave % WN) * 64 + (lane & 31), c1 = c0 + 32;
+    float2 b;
+    b.x = (t.bias != nullptr && c0 < cols) ? t.bias[c0] : 0.0f;
+    b.y = (t.bias != nullptr && c1 < cols) ? t.bias[c1] : 0.0f;
+    return b;
+  }
+
   // accumulators -> global memory without the LDS round trip: for a fixed register the 32 low lanes
   // hold 32 consecutive columns of one row (a 128-byte segment) and the high lanes the row 4 below.
+  // The added / residual values of all 16 registers are requested first and consumed afterwards, so
+  // their latencies overlap instead of adding up.
   template <bool RELU>
   __device__ static void store_direct(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
-                                      float* __restrict__ out, int64_t out_ld, const Tail& t) {
+                                      float* __restrict__ out, int64_t out_ld, const Tail& t, float2 bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int lo = lane & 31, hi = lane >> 5;
     const int c0 = col0 + wc * 64 + lo, c1 = c0 + 32;
     const bool ok0 = c0 < cols, ok1 = c1 < cols;
-    const float b0 = (t.bias != nullptr && ok0) ? t.bias[c0] : 0.0f;
-    const float b1 = (t.bias != nullptr && ok1) ? t.bias[c1] : 0.0f;
+    const int c0c = ok0 ? c0 : 0, c1c = ok1 ? c1 : 0;  // in-bounds columns for the unconditional loads
     const bool drop = t.drop_p > 0.0f;
     const float keep_scale = drop ? 1.0f / (1.0f - t.drop_p) : 1.0f;
     const uint64_t seed = t.seed + ((drop && t.seed_ptr != nullptr) ? *t.seed_ptr : 0ull);
+    const int row_base = row0 + wr * 32 + 4 * hi;
+    float add0[16], add1[16], res0[16], res1[16];
+    if (t.add != nullptr) {
+      int ar[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ar[r] = min(row_base + (r & 3) + 8 * (r >> 2), rows - 1);
+      if (t.add_index != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ar[r] = t.add_index[ar[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ar[r] = min(max(ar[r], 0), t.add_rows - 1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        add0[r] = t.add[(int64_t)ar[r] * t.add_ld + c0c];
+        add1[r] = t.add[(int64_t)ar[r] * t.add_ld + c1c];
+      }
+    }
+    if (t.residual != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gr = min(row_base + (r & 3) + 8 * (r >> 2), rows - 1);
+        res0[r] = t.residual[(int64_t)gr * t.res_ld + c0c];
+        res1[r] = t.residual[(int64_t)gr * t.res_ld + c1c];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int gr = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int gr = row_base + (r & 3) + 8 * (r >> 2);
       if (gr < rows) {
-        float v0 = acc0[r] + b0, v1 = acc1[r] + b1;
+        float v0 = acc0[r] + bias.x, v1 = acc1[r] + bias.y;
         if (t.add != nullptr) {
-          const int64_t ar = t.add_index != nullptr ? min(max(t.add_index[gr], 0), t.add_rows - 1) : gr;
-          if (ok0) v0 += t.add[ar * t.add_ld + c0];
-          if (ok1) v1 += t.add[ar * t.add_ld + c1];
+          v0 += add0[r];
+          v1 += add1[r];
         }
         if (RELU) {
           v0 = fmaxf(v0, 0.0f);
@@ -320,8 +377,8 @@ struct Core {
           v1 = uniform01(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
         }
         if (t.residual != nullptr) {
-          if (ok0) v0 += t.residual[(int64_t)gr * t.res_ld + c0];
-          if (ok1) v1 += t.residual[(int64_t)gr * t.res_ld + c1];
+          v0 += res0[r];
+          v1 += res1[r];
         }
         if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
         if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
@@ -354,9 +411,20 @@ __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   Operand xa = a.x, wa = a.w;
   f32x16 acc0, acc1;
+  const float2 bias2 = C::bias_pair(a.t, col0, a.N);
+  HIVT_STAMP(0);
+#ifdef HIVT_PROBE
+  if (threadIdx.x == 0 && d_probe != nullptr) {  // where the block ran: HW_ID and XCC_ID registers
+    long long* slot = d_probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    slot[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+    slot[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+  }
+#endif
   C::accumulate(xa, wa, row0, col0, 0, a.x.red, lds, acc0, acc1);
+  HIVT_STAMP(2);
   if (EPI == EPI_NONE || EPI == EPI_RELU) {
-    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.t);
+    C::template store_direct<EPI == EPI_RELU>(acc0, acc1, row0, col0, a.M, a.N, a.y, a.y_ld, a.t, bias2);
+    HIVT_STAMP(3);
     return;
   }
   // LayerNorm over the full output row: the row is spread over the waves, so it goes through LDS;
@@ -451,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
-  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, Tail{});
+  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, Tail{}, make_float2(0.0f, 0.0f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -829,6 +897,12 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
 }  // namespace hivt
 
 using namespace hivt;
+
+#ifdef HIVT_PROBE
+extern "C" int hivt_probe_set(long long* buffer) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(d_probe), &buffer, sizeof(buffer));
+}
+#endif
 
 extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
                                const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,

@@ -26,7 +26,7 @@ from .decoder import MLPDecoder
 from .global_interactor import GlobalInteractor
 from .local_encoder import LocalEncoder
 from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss,
-                     SoftTargetCrossEntropyLoss, fused_supervised_losses)
+                     SoftTargetCrossEntropyLoss, fused_supervised_losses, join_critic_streams)
 
 
 class HiVT(nn.Module):
@@ -208,6 +208,8 @@ class HiVT(nn.Module):
             d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
             opt_d.zero_grad(set_to_none=True)
             d_loss.backward()
+            if real.is_cuda:
+                join_critic_streams(real.device)
             update("critic", opt_d)
         # generator update (models/hivt.py:317-327); critic weight gradients of this backward would be
         # discarded by the next opt_d.zero_grad(), so they are not computed at all
@@ -218,6 +220,8 @@ class HiVT(nn.Module):
             g_total = reg_loss + cls_loss + g_adv
             opt_g.zero_grad(set_to_none=True)
             g_total.backward()
+            if fake.is_cuda:
+                join_critic_streams(fake.device)
         finally:
             for p in critic_params:
                 p.requires_grad_(True)

@@ -4,13 +4,57 @@ losses that take all agents with a keep-mask instead of boolean-indexed subsets.
 from __future__ import annotations
 
 import math
-from typing import Dict, Tuple
+from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+
+# The critics are independent small networks (a few thousand rows each), so one of them fills a fraction
+# of the GPU.  On the GPU every critic gets a stream of its own: their forward passes overlap, and so do
+# their backward passes (autograd replays each operation on the stream of its forward).
+CONCURRENT_CRITICS = True
+_side_streams: Dict[int, List["torch.cuda.Stream"]] = {}
+
+
+def _streams(device: torch.device, n: int):
+    pool = _side_streams.setdefault(device.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def per_critic(critics: dict, inputs: Sequence[torch.Tensor], body: Callable):
+    """``[body(name, critic) for name, critic in critics.items()]`` (tuples of tensors).  For GPU
+    inputs each critic runs on its own stream, ordered after the current stream's work so far; the
+    current stream then waits for all of them.  ``inputs`` are the tensors ``body`` reads."""
+    if not (CONCURRENT_CRITICS and len(critics) > 1 and inputs[0].is_cuda):
+        return [body(name, critic) for name, critic in critics.items()]
+    main = torch.cuda.current_stream(inputs[0].device)
+    streams = _streams(inputs[0].device, len(critics))
+    outs = []
+    for s, (name, critic) in zip(streams, critics.items()):
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            outs.append(body(name, critic))
+    for s, out in zip(streams, outs):
+        main.wait_stream(s)
+        for t in out:
+            t.record_stream(main)  # produced on s, consumed on the current stream
+        for t in inputs:
+            t.record_stream(s)     # produced on the current stream, read on s
+    return outs
+
+
+def join_critic_streams(device: torch.device) -> None:
+    """Makes the current stream wait for everything queued on the critics' streams (after a backward
+    pass, before the optimizer or a collective touches the critics' gradients)."""
+    main = torch.cuda.current_stream(device)
+    for s in _side_streams.get(device.index, []):
+        main.wait_stream(s)
 
 
 def _reduce(x: torch.Tensor, reduction: str) -> torch.Tensor:
@@ -84,17 +128,22 @@ class AdversarialDiscriminatorLoss(nn.Module):
         Valid because every term is a per-sample mean and the critics act row-wise."""
         w = keep.to(real.dtype)
         cnt = w.sum().clamp(min=1.0)
-        total, logs = 0.0, {}
-        for name, critic in critics.items():
+        real, fake = real.detach(), fake.detach()
+
+        def one(name, critic):
             # score and ||d score / d input||^2 of the real samples come from ONE critic call, as in the
             # reference (hinge and R1 share the forward pass, models/hivt.py:244-252)
-            d_real, grad_norm2 = critic.scores_and_input_grad_norm(real.detach())
-            d_fake = critic(fake.detach())
+            d_real, grad_norm2 = critic.scores_and_input_grad_norm(real)
+            d_fake = critic(fake)
             r1 = (grad_norm2 * w).sum() / cnt
             loss = (F.relu(1.0 - d_real) * w).sum() / cnt + (F.relu(1.0 + d_fake) * w).sum() / cnt + self.lambda_r1 * r1
+            return loss, r1.detach()
+
+        total, logs = 0.0, {}
+        for name, (loss, r1) in zip(critics, per_critic(critics, (real, fake, w, cnt), one)):
             total = total + loss
             logs[f"d_loss_{name}"] = loss.detach()
-            logs[f"r1_{name}"] = r1.detach()
+            logs[f"r1_{name}"] = r1
         return total, logs
 
 
@@ -117,8 +166,7 @@ class AdversarialGeneratorLoss(nn.Module):
         w = keep.to(fake.dtype)
         cnt = w.sum().clamp(min=1.0)
         total, logs = 0.0, {}
-        for name, critic in critics.items():
-            g = -(critic(fake) * w).sum() / cnt
+        for name, (g,) in zip(critics, per_critic(critics, (fake, w, cnt), lambda _, c: (-(c(fake) * w).sum() / cnt,))):
             total = total + g
             logs[f"g_loss_{name}"] = g.detach()
         return self.lambda_adv * total, logs
