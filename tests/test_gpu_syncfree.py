@@ -191,3 +191,44 @@ def test_bucketed_all_reduce_path_on_gpu_single_rank():
         assert all(bool(torch.isfinite(v).all()) for v in dp_model.parameters())
     finally:
         dist.destroy_process_group()
+
+
+def test_critics_on_their_own_streams_equal_the_sequential_run():
+    """The critics' losses run on one stream per critic (dropout 0.1 active): values, critic gradients
+    and the gradient handed back to the generator must be bit-identical to the single-stream run."""
+    from hivt_gan_amd import losses as L
+    torch.manual_seed(3)
+    critics = torch.nn.ModuleDict({"short": hv.ShortScaleCritic(horizon=10), "mid": hv.MidScaleCritic(horizon=20),
+                                   "long": hv.LongScaleCritic(horizon=30)}).to(DEV).train()
+    state = copy.deepcopy(critics.state_dict())  # the power-iteration vectors advance with every call
+    B = 2600
+    real = torch.randn(B, 30, 2, device=DEV)
+    fake = torch.randn(B, 30, 2, device=DEV, requires_grad=True)
+    keep = torch.rand(B, device=DEV) > 0.2
+    d_fn, g_fn = hv.AdversarialDiscriminatorLoss(lambda_r1=1.0), hv.AdversarialGeneratorLoss(lambda_adv=1.0)
+
+    def run(concurrent):
+        L.CONCURRENT_CRITICS = concurrent
+        critics.load_state_dict(state)
+        torch.manual_seed(11)  # dropout seeds are drawn from the host generator
+        for p in critics.parameters():
+            p.grad = None
+        fake.grad = None
+        d, d_logs = d_fn.forward_masked(critics, real, fake, keep)
+        d.backward()
+        L.join_critic_streams(DEV)
+        d_grads = [p.grad.clone() for p in critics.parameters()]
+        g, g_logs = g_fn.forward_masked(critics, fake, keep)
+        g.backward()
+        L.join_critic_streams(DEV)
+        return d.detach(), g.detach(), d_grads, fake.grad.clone(), {**d_logs, **g_logs}
+
+    try:
+        seq = run(False)
+        par = run(True)
+    finally:
+        L.CONCURRENT_CRITICS = True
+    assert torch.equal(seq[0], par[0]) and torch.equal(seq[1], par[1])
+    assert all(torch.equal(a, b) for a, b in zip(seq[2], par[2]))
+    assert torch.equal(seq[3], par[3]) and float(seq[3].abs().max()) > 0
+    assert set(seq[4]) == set(par[4]) and all(torch.equal(seq[4][k], par[4][k]) for k in seq[4])
