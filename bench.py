@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="keep the default launch schedule (no timing of alternatives)")
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
     ap.add_argument("--cpu-scenes", type=int, default=8)
@@ -158,6 +159,8 @@ def main():
         batch["edge_plan"] = None     # edge construction belongs to the step
         return trainer.step(batch)
 
+    # launch schedule chosen by measurement (untimed set-up, like the capacity calibration above)
+    tuned = trainer.tune(run_step) if not args.no_tune else {}
     for i in range(args.warmup):
         run_step(i)
     records = []
@@ -209,7 +212,7 @@ def main():
                                    f"nuScenes-shaped scenes per GPU per step, dropout 0.1, AdamW x2",
                        "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
                        "guards": "host" if args.host_guards else "device",
-                       "discarded_steps": trainer.overflowed_steps()},
+                       "discarded_steps": trainer.overflowed_steps(), "tuned": tuned},
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
         }

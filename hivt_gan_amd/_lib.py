@@ -72,6 +72,10 @@ SIGNATURES = {
                                 _P, _P, _P]),
     "hivt_critic_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                 c_size_t, _P]),
+    "hivt_hinge_r1_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_hinge_r1_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P]),
+    "hivt_weighted_mean_fwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_weighted_mean_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
@@ -101,21 +105,51 @@ def load() -> ctypes.CDLL:
 
 
 _functions = {}
+_fast = None  # the generated CPython binding of the same entry points, when it has been built
+
+
+def _load_fast():
+    """``_hivt_fast`` (built next to the library from ``csrc/gen_fastcall.py``): one METH_FASTCALL
+    wrapper per entry point.  Same functions, same arguments; a call costs a fraction of a microsecond
+    of host time instead of several with ctypes.  Absent module -> the ctypes binding serves."""
+    global _fast
+    if _fast is None:
+        load()  # the shared library must be there either way: no fallback for the kernels
+        try:
+            from . import _hivt_fast
+            _hivt_fast.set_error_class(HivtLibraryError)
+            _fast = _hivt_fast
+        except ImportError:
+            _fast = False
+    return _fast
 
 
 def _function(name: str):
     fn = _functions.get(name)
     if fn is None:
-        fn = _functions[name] = getattr(load(), name)
+        fast = _load_fast()
+        if fast and hasattr(fast, name):
+            fn = getattr(fast, name)
+        else:
+            cfn = getattr(load(), name)
+            if cfn.restype is c_int and name != "hivt_version":
+                def fn(*args, _cfn=cfn, _name=name):
+                    rc = _cfn(*args)
+                    if rc != 0:
+                        msg = load().hivt_last_error().decode("utf-8", "replace")
+                        raise HivtLibraryError(f"{_name} failed with code {rc}: {msg}")
+            else:
+                fn = cfn
+        _functions[name] = fn
     return fn
 
 
 def call(name: str, *args) -> None:
-    """Invoke an ``int``-returning entry point and raise on a non-zero return code."""
-    rc = _function(name)(*args)
-    if rc != 0:
-        msg = load().hivt_last_error().decode("utf-8", "replace")
-        raise HivtLibraryError(f"{name} failed with code {rc}: {msg}")
+    """Invoke an ``int``-returning entry point; a non-zero return code raises ``HivtLibraryError``."""
+    fn = _functions.get(name)
+    if fn is None:
+        fn = _function(name)
+    fn(*args)
 
 
 _sizes = {}

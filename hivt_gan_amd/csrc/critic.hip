@@ -168,6 +168,81 @@ Scratch carve(const Shape& s, void* ws) {
     if (rc__ != HIVT_OK) return rc__; \
   } while (0)
 
+// Block-wide sum in a fixed order (pairwise tree over the 256 partial sums): independent of scheduling.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int half = 128; half > 0; half >>= 1) {
+    if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+    __syncthreads();
+  }
+  const float total = red[0];
+  __syncthreads();
+  return total;
+}
+
+// out[0] = mean_w relu(1 - s_real) + mean_w relu(1 + s_fake) + lambda * r1,  out[1] = r1 = mean_w grad_norm2,
+// mean_w(v) = sum_i w_i v_i / count.  One block; each thread owns a fixed strided subset.
+__global__ __launch_bounds__(256) void hinge_r1_fwd_kernel(const float* __restrict__ s_real,
+                                                           const float* __restrict__ grad_norm2,
+                                                           const float* __restrict__ s_fake,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ count, int64_t B, float lambda,
+                                                           float* __restrict__ out) {
+  __shared__ float red[256];
+  float a = 0.0f, b = 0.0f, c = 0.0f;
+  for (int64_t i = threadIdx.x; i < B; i += 256) {
+    const float wi = w[i];
+    a += fmaxf(1.0f - s_real[i], 0.0f) * wi;
+    b += fmaxf(1.0f + s_fake[i], 0.0f) * wi;
+    c += grad_norm2[i] * wi;
+  }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  c = block_sum_256(c, red);
+  if (threadIdx.x == 0) {
+    const float cnt = *count;
+    const float r1 = c / cnt;
+    out[0] = (a / cnt + b / cnt) + lambda * r1;
+    out[1] = r1;
+  }
+}
+
+__global__ __launch_bounds__(256) void hinge_r1_bwd_kernel(const float* __restrict__ g_loss,
+                                                           const float* __restrict__ s_real,
+                                                           const float* __restrict__ s_fake,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ count, int64_t B, float lambda,
+                                                           float* __restrict__ g_real, float* __restrict__ g_norm2,
+                                                           float* __restrict__ g_fake) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  const float unit = *g_loss * w[i] / *count;
+  g_real[i] = (1.0f - s_real[i] > 0.0f) ? -unit : 0.0f;
+  g_fake[i] = (1.0f + s_fake[i] > 0.0f) ? unit : 0.0f;
+  g_norm2[i] = lambda * unit;
+}
+
+// out = scale * sum_i w_i s_i / count, and its gradient
+__global__ __launch_bounds__(256) void weighted_mean_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                                const float* __restrict__ count, int64_t B, float scale,
+                                                                float* __restrict__ out) {
+  __shared__ float red[256];
+  float a = 0.0f;
+  for (int64_t i = threadIdx.x; i < B; i += 256) a += s[i] * w[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) out[0] = scale * (a / *count);
+}
+
+__global__ __launch_bounds__(256) void weighted_mean_bwd_kernel(const float* __restrict__ g_out,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ count, int64_t B, float scale,
+                                                                float* __restrict__ g_s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < B) g_s[i] = scale * *g_out * w[i] / *count;
+}
+
+
 }  // namespace
 }  // namespace hivt
 
@@ -346,5 +421,53 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
     }
     HIVT_CHECK_LAUNCH(what);
   }
+  return HIVT_OK;
+}
+
+extern "C" int hivt_hinge_r1_fwd(const float* s_real, const float* grad_norm2, const float* s_fake, const float* w,
+                                 const float* count, int64_t B, float lambda_r1, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_hinge_r1_fwd";
+  HIVT_REQUIRE(B >= 0, HIVT_ERR_ARG, "%s: bad size", what);
+  HIVT_REQUIRE(count && out && (B == 0 || (s_real && grad_norm2 && s_fake && w)), HIVT_ERR_ARG, "%s: null pointer",
+               what);
+  hipLaunchKernelGGL(hinge_r1_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s_real, grad_norm2, s_fake, w,
+                     count, B, lambda_r1, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_fake, const float* w,
+                                 const float* count, int64_t B, float lambda_r1, float* g_real, float* g_norm2,
+                                 float* g_fake, hivt_stream_t stream) {
+  const char* what = "hivt_hinge_r1_bwd";
+  HIVT_REQUIRE(B >= 0, HIVT_ERR_ARG, "%s: bad size", what);
+  if (B == 0) return HIVT_OK;
+  HIVT_REQUIRE(g_loss && s_real && s_fake && w && count && g_real && g_norm2 && g_fake, HIVT_ERR_ARG,
+               "%s: null pointer", what);
+  hipLaunchKernelGGL(hinge_r1_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_loss,
+                     s_real, s_fake, w, count, B, lambda_r1, g_real, g_norm2, g_fake);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_weighted_mean_fwd(const float* s, const float* w, const float* count, int64_t B, float scale,
+                                      float* out, hivt_stream_t stream) {
+  const char* what = "hivt_weighted_mean_fwd";
+  HIVT_REQUIRE(B >= 0, HIVT_ERR_ARG, "%s: bad size", what);
+  HIVT_REQUIRE(count && out && (B == 0 || (s && w)), HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(weighted_mean_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, w, count, B, scale, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_weighted_mean_bwd(const float* g_out, const float* w, const float* count, int64_t B, float scale,
+                                      float* g_s, hivt_stream_t stream) {
+  const char* what = "hivt_weighted_mean_bwd";
+  HIVT_REQUIRE(B >= 0, HIVT_ERR_ARG, "%s: bad size", what);
+  if (B == 0) return HIVT_OK;
+  HIVT_REQUIRE(g_out && w && count && g_s, HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(weighted_mean_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g_out, w, count, B, scale, g_s);
+  HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

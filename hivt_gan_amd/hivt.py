@@ -25,6 +25,7 @@ from .critics import LongScaleCritic, MidScaleCritic, ShortScaleCritic
 from .decoder import MLPDecoder
 from .global_interactor import GlobalInteractor
 from .local_encoder import LocalEncoder
+from .optim import FusedAdamW
 from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss,
                      SoftTargetCrossEntropyLoss, fused_supervised_losses, join_critic_streams)
 
@@ -90,12 +91,17 @@ class HiVT(nn.Module):
         """AdamW (all generator parameters decayed, ``models/hivt.py:428,444``) with cosine annealing;
         a second AdamW without decay for the critics (``models/hivt.py:453``)."""
         fused = next(self.parameters()).is_cuda
+
+        def adamw(params, lr, weight_decay):
+            if fused:
+                return FusedAdamW(params, lr=lr, weight_decay=weight_decay)
+            return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+
         if not self.use_gan:
-            opt = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.weight_decay, fused=fused)
+            opt = adamw(self.parameters(), self.lr, self.weight_decay)
             return [opt], [torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=self.T_max, eta_min=0.0)]
-        opt_g = torch.optim.AdamW(self.generator_parameters(), lr=self.lr, weight_decay=self.weight_decay,
-                                  fused=fused)
-        opt_d = torch.optim.AdamW(self.critic_parameters(), lr=self.critic_lr, weight_decay=0.0, fused=fused)
+        opt_g = adamw(self.generator_parameters(), self.lr, self.weight_decay)
+        opt_d = adamw(self.critic_parameters(), self.critic_lr, 0.0)
         return [opt_g, opt_d], [torch.optim.lr_scheduler.CosineAnnealingLR(opt_g, T_max=self.T_max, eta_min=0.0)]
 
     # ------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@ losses that take all agents with a keep-mask instead of boolean-indexed subsets.
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Dict, List, Sequence, Tuple
 
 import torch
@@ -16,7 +17,7 @@ from . import ops
 # The critics are independent small networks (a few thousand rows each), so one of them fills a fraction
 # of the GPU.  On the GPU every critic gets a stream of its own: their forward passes overlap, and so do
 # their backward passes (autograd replays each operation on the stream of its forward).
-CONCURRENT_CRITICS = True
+CONCURRENT_CRITICS = os.environ.get("HIVT_CONCURRENT_CRITICS", "1") != "0"
 _side_streams: Dict[int, List["torch.cuda.Stream"]] = {}
 
 
@@ -36,8 +37,9 @@ def per_critic(critics: dict, inputs: Sequence[torch.Tensor], body: Callable):
     main = torch.cuda.current_stream(inputs[0].device)
     streams = _streams(inputs[0].device, len(critics))
     outs = []
+    ready = main.record_event()
     for s, (name, critic) in zip(streams, critics.items()):
-        s.wait_stream(main)
+        s.wait_event(ready)
         with torch.cuda.stream(s):
             outs.append(body(name, critic))
     for s, out in zip(streams, outs):
@@ -135,6 +137,8 @@ class AdversarialDiscriminatorLoss(nn.Module):
             # reference (hinge and R1 share the forward pass, models/hivt.py:244-252)
             d_real, grad_norm2 = critic.scores_and_input_grad_norm(real)
             d_fake = critic(fake)
+            if d_real.is_cuda:  # the three masked means and their sum in one launch
+                return ops.hinge_r1_loss(d_real, grad_norm2, d_fake, w, cnt, self.lambda_r1)
             r1 = (grad_norm2 * w).sum() / cnt
             loss = (F.relu(1.0 - d_real) * w).sum() / cnt + (F.relu(1.0 + d_fake) * w).sum() / cnt + self.lambda_r1 * r1
             return loss, r1.detach()
@@ -166,7 +170,13 @@ class AdversarialGeneratorLoss(nn.Module):
         w = keep.to(fake.dtype)
         cnt = w.sum().clamp(min=1.0)
         total, logs = 0.0, {}
-        for name, (g,) in zip(critics, per_critic(critics, (fake, w, cnt), lambda _, c: (-(c(fake) * w).sum() / cnt,))):
+        def one(_, critic):
+            scores = critic(fake)
+            if scores.is_cuda:
+                return (ops.weighted_mean(scores, w, cnt, -1.0),)
+            return (-(scores * w).sum() / cnt,)
+
+        for name, (g,) in zip(critics, per_critic(critics, (fake, w, cnt), one)):
             total = total + g
             logs[f"g_loss_{name}"] = g.detach()
         return self.lambda_adv * total, logs

@@ -257,7 +257,7 @@ def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args
     ev1 = torch.cuda.Event(enable_timing=True)
     ev0.record(stream)  # creates the underlying events; the timed launch re-records them with the
     ev1.record(stream)  # kernel's own start / stop time stamps
-    _lib.call(name + "_timed", *args, ctypes.c_void_p(ev0.cuda_event), ctypes.c_void_p(ev1.cuda_event))
+    _lib.call(name + "_timed", *args, int(ev0.cuda_event), int(ev1.cuda_event))
     rec.append((kind, tag, n, live, d_model, heads, node_terms, ev0, ev1))
 
 
@@ -907,3 +907,69 @@ def critic_scores(x: torch.Tensor, weights, biases, neg_slope: float, dropout_p:
     params = [t for pair in zip(weights, biases) for t in pair]
     cfg = (float(neg_slope), p, _fresh_seed() if p > 0.0 else 0, bool(with_input_grad_norm))
     return _Critic.apply(x, cfg, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# Per-scale adversarial loss terms (one launch instead of a dozen framework reductions)
+# --------------------------------------------------------------------------------------------
+class _HingeR1Loss(torch.autograd.Function):
+    """(loss, r1) of one critic scale; gradients flow into the two score vectors and the gradient norms."""
+
+    @staticmethod
+    def forward(ctx, s_real, grad_norm2, s_fake, w, count, lambda_r1):
+        _need_gpu(s_real, grad_norm2, s_fake, w, count)
+        b = s_real.shape[0]
+        s_real, grad_norm2, s_fake, w = (t.contiguous() for t in (s_real, grad_norm2, s_fake, w))
+        out = torch.empty(2, dtype=torch.float32, device=s_real.device)
+        _lib.call("hivt_hinge_r1_fwd", _p(s_real), _p(grad_norm2), _p(s_fake), _p(w), _p(count), b, float(lambda_r1),
+                  _p(out), _stream(s_real))
+        ctx.save_for_backward(s_real, s_fake, w, count)
+        ctx.lambda_r1 = float(lambda_r1)
+        loss, r1 = out[0], out[1]
+        ctx.mark_non_differentiable(r1)
+        return loss, r1
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loss, _g_r1):
+        s_real, s_fake, w, count = ctx.saved_tensors
+        b = s_real.shape[0]
+        g_loss = g_loss.contiguous()
+        g_real, g_norm2, g_fake = (torch.empty_like(s_real) for _ in range(3))
+        _lib.call("hivt_hinge_r1_bwd", _p(g_loss), _p(s_real), _p(s_fake), _p(w), _p(count), b, ctx.lambda_r1, _p(g_real),
+                  _p(g_norm2), _p(g_fake), _stream(s_real))
+        return g_real, g_norm2, g_fake, None, None, None
+
+
+def hinge_r1_loss(s_real: torch.Tensor, grad_norm2: torch.Tensor, s_fake: torch.Tensor, w: torch.Tensor,
+                  count: torch.Tensor, lambda_r1: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(mean_w relu(1 - s_real) + mean_w relu(1 + s_fake) + lambda_r1 * r1, r1)`` with
+    ``r1 = mean_w grad_norm2`` and ``mean_w(v) = sum(w * v) / count`` (``count``: device scalar)."""
+    return _HingeR1Loss.apply(s_real, grad_norm2, s_fake, w, count, lambda_r1)
+
+
+class _WeightedMean(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, s, w, count, scale):
+        _need_gpu(s, w, count)
+        s, w = s.contiguous(), w.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=s.device)
+        _lib.call("hivt_weighted_mean_fwd", _p(s), _p(w), _p(count), s.shape[0], float(scale), _p(out), _stream(s))
+        ctx.save_for_backward(w, count)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        w, count = ctx.saved_tensors
+        g_s = torch.empty_like(w)
+        _lib.call("hivt_weighted_mean_bwd", _p(g_out.contiguous()), _p(w), _p(count), w.shape[0], ctx.scale, _p(g_s),
+                  _stream(w))
+        return g_s, None, None, None
+
+
+def weighted_mean(s: torch.Tensor, w: torch.Tensor, count: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """``scale * sum(w * s) / count`` as a 0-d tensor (``count``: device scalar)."""
+    return _WeightedMean.apply(s, w, count, scale)

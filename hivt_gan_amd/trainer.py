@@ -134,6 +134,36 @@ class GanTrainer:
         self._overflows = over if self._overflows is None else self._overflows + over
         return logs
 
+    def tune(self, run_step, rounds: int = 2, steps: int = 4) -> Dict[str, bool]:
+        """Picks the launch schedule by measurement: ``run_step(i)`` (one training step on some batch) is
+        timed with the critics on one stream and with a stream per critic, alternating ``rounds`` times,
+        and the faster setting stays.  Which one wins depends on whether the host or the GPU bounds the
+        step on the machine at hand.  Under data parallelism every rank adopts the majority's choice."""
+        import time
+        from . import losses
+        if not torch.cuda.is_available():
+            return {"critic_streams": losses.CONCURRENT_CRITICS}
+        spent = {True: 0.0, False: 0.0}
+        i = 0
+        for _ in range(rounds):
+            for mode in (True, False):
+                losses.CONCURRENT_CRITICS = mode
+                run_step(i)
+                i += 1
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run_step(i)
+                    i += 1
+                torch.cuda.synchronize()
+                spent[mode] += time.perf_counter() - t0
+        vote = torch.tensor([1.0 if spent[True] <= spent[False] else 0.0], device="cuda")
+        if self.distributed:
+            dist.all_reduce(vote)
+            vote /= dist.get_world_size()
+        losses.CONCURRENT_CRITICS = bool(vote.item() >= 0.5)
+        return {"critic_streams": losses.CONCURRENT_CRITICS}
+
     def overflowed_steps(self) -> int:
         """Steps discarded because a filtered edge list exceeded its capacity (reads the device)."""
         return int(self._overflows.item()) if self._overflows is not None else 0

@@ -406,6 +406,26 @@ int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x,
                     const float* saved, float* const* dw, float* const* dbias, float* dx, void* workspace,
                     size_t workspace_bytes, hivt_stream_t stream);
 
+/* Critic loss of one scale (losses/adv_losses.py:36-58 with losses/r1_regularization.py:27-36), over all
+ * B rows with per-row weights w (0/1 keep mask) instead of boolean-indexed subsets:
+ *   out[0] = sum_i w_i relu(1 - s_real_i) / count + sum_i w_i relu(1 + s_fake_i) / count + lambda_r1 * out[1]
+ *   out[1] = sum_i w_i grad_norm2_i / count                       (the R1 penalty)
+ * count is a device scalar (number of kept rows, at least 1).  One block, fixed summation order. */
+int hivt_hinge_r1_fwd(const float* s_real, const float* grad_norm2, const float* s_fake, const float* w,
+                      const float* count, int64_t B, float lambda_r1, float* out, hivt_stream_t stream);
+
+/* Gradient of out[0] above with respect to s_real, grad_norm2 and s_fake; g_loss is a device scalar. */
+int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_fake, const float* w,
+                      const float* count, int64_t B, float lambda_r1, float* g_real, float* g_norm2, float* g_fake,
+                      hivt_stream_t stream);
+
+/* Generator's adversarial term of one scale (losses/adv_losses.py:91-98): out = scale * sum_i w_i s_i / count
+ * (scale = -1 for -mean D(fake)), and its gradient g_s_i = scale * g_out * w_i / count. */
+int hivt_weighted_mean_fwd(const float* s, const float* w, const float* count, int64_t B, float scale, float* out,
+                           hivt_stream_t stream);
+int hivt_weighted_mean_bwd(const float* g_out, const float* w, const float* count, int64_t B, float scale, float* g_s,
+                           hivt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -654,3 +654,41 @@ def test_fused_linear_dropout_and_residual_epilogue(relu):
     y_eval = ops.fused_linear(x, lin.weight, lin.bias, relu=relu, dropout_p=p, training=False, residual=res)
     ref_eval = torch.relu(lin(x)) if relu else lin(x) + res
     close(y_eval, ref_eval, 1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 300, 2623])
+def test_fused_adversarial_loss_terms_match_framework_ops(B):
+    """hivt_hinge_r1_fwd/bwd and hivt_weighted_mean_fwd/bwd against the framework expressions of
+    losses/adv_losses.py (masked means with a keep weight per row)."""
+    import torch.nn.functional as F
+    torch.manual_seed(B)
+    dev = torch.device("cuda", 0)
+    s_real = (torch.randn(B, device=dev) * 1.5).requires_grad_(True)
+    s_fake = (torch.randn(B, device=dev) * 1.5).requires_grad_(True)
+    gn2 = torch.rand(B, device=dev).requires_grad_(True)
+    w = (torch.rand(B, device=dev) > 0.3).float()
+    cnt = w.sum().clamp(min=1.0)
+    lam = 0.7
+    loss, r1 = ops.hinge_r1_loss(s_real, gn2, s_fake, w, cnt, lam)
+    (loss * 1.3).backward()
+    got = [t.grad.clone() for t in (s_real, gn2, s_fake)]
+    for t in (s_real, gn2, s_fake):
+        t.grad = None
+    r1_ref = (gn2 * w).sum() / cnt
+    ref = (F.relu(1.0 - s_real) * w).sum() / cnt + (F.relu(1.0 + s_fake) * w).sum() / cnt + lam * r1_ref
+    (ref * 1.3).backward()
+    assert not r1.requires_grad
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(r1) - float(r1_ref)) <= 1e-5 * max(1.0, abs(float(r1_ref)))
+    for g, t in zip(got, (s_real, gn2, s_fake)):
+        assert float((g - t.grad).abs().max()) <= 1e-6 * max(1e-6, float(t.grad.abs().max()))
+    for t in (s_real, gn2, s_fake):
+        t.grad = None
+    g = ops.weighted_mean(s_fake, w, cnt, -1.0)
+    (g * 0.4).backward()
+    got = s_fake.grad.clone()
+    s_fake.grad = None
+    ref = -(s_fake * w).sum() / cnt
+    (ref * 0.4).backward()
+    assert abs(float(g) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert float((got - s_fake.grad).abs().max()) <= 1e-6 * max(1e-6, float(s_fake.grad.abs().max()))

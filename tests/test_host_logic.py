@@ -194,6 +194,30 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().hivt_last_error() == b""
 
 
+def test_generated_binding_covers_the_same_entry_points():
+    """The generated CPython binding must expose every entry point of the header, answer the size queries
+    like the ctypes binding, and raise the library's error type with the library's message."""
+    fast = _lib._load_fast()
+    assert fast, "hivt_gan_amd/_hivt_fast.so has not been built (make -C hivt_gan_amd/csrc)"
+    lib = _lib.load()
+    for name in _lib.SIGNATURES:
+        assert hasattr(fast, name), f"{name} has no generated wrapper"
+    assert fast.hivt_version() == lib.hivt_version()
+    widths = (ctypes.c_int32 * 3)(20, 128, 128)
+    assert fast.hivt_critic_workspace_bytes(100, 2, widths) == lib.hivt_critic_workspace_bytes(100, 2, widths)
+    assert fast.hivt_linear_wgrad_workspace_bytes(1000, 128, 128) == lib.hivt_linear_wgrad_workspace_bytes(1000, 128, 128)
+    # argument checks run before anything touches a GPU: an unknown epilogue code is refused
+    args = [0, 128, 0, 128, None, None, 0, None, 0, None, None, 1e-5, 9, 1.0, 0.0, 0, None, None, 0, 5, 128, 128, 0, 128,
+            None, 0, None, 0]
+    with pytest.raises(_lib.HivtLibraryError, match="unknown epilogue 9"):
+        fast.hivt_linear_fwd(*args)
+    with pytest.raises(TypeError):
+        fast.hivt_linear_fwd(*args[:-1])
+    args[12] = 0
+    args[19] = 0  # no rows: returns before any launch
+    assert fast.hivt_linear_fwd(*args) is None
+
+
 def test_kernels_refuse_cpu_tensors():
     from hivt_gan_amd import ops
     with pytest.raises(RuntimeError, match="GPU only"):
