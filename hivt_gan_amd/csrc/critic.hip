@@ -323,9 +323,20 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
   const char* what = "hivt_critic_bwd";
   Shape s;
   HIVT_TRY(make_shape(what, B, layers, widths, s));
-  HIVT_REQUIRE(dw && dbias, HIVT_ERR_ARG, "%s: null gradient arrays", what);
-  for (int l = 0; l <= layers; ++l) HIVT_REQUIRE(dw[l] && dbias[l], HIVT_ERR_ARG, "%s: null gradient (layer %d)", what, l);
+  // dw == dbias == null: the parameters are frozen, only dx (the gradient of the scores) is wanted
+  const bool params = dw != nullptr || dbias != nullptr;
+  HIVT_REQUIRE(!params || (dw && dbias), HIVT_ERR_ARG, "%s: dw and dbias go together", what);
+  HIVT_REQUIRE(params || (g_norm2 == nullptr && dx != nullptr), HIVT_ERR_ARG,
+               "%s: without parameter gradients the call computes dx from g_scores only", what);
+  if (params)
+    for (int l = 0; l <= layers; ++l)
+      HIVT_REQUIRE(dw[l] && dbias[l], HIVT_ERR_ARG, "%s: null gradient (layer %d)", what, l);
   hipStream_t st = (hipStream_t)stream;
+  if (!params && (B == 0 || g_scores == nullptr)) {
+    if (B > 0) zero_words(dx, B * s.w[0], st);
+    HIVT_CHECK_LAUNCH(what);
+    return HIVT_OK;
+  }
   if (B == 0 || (g_scores == nullptr && g_norm2 == nullptr)) {
     for (int l = 1; l <= layers; ++l) {
       zero_words(dw[l - 1], (int64_t)s.w[l] * s.w[l - 1], st);
@@ -346,8 +357,9 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
   if (g_scores != nullptr) {
     // ---- gradient of the scores: ordinary backward through the layers ----
     // output layer: dw_o = g^T h_L, db_o = sum g
-    HIVT_TRY(hivt_linear_wgrad(g_scores, 1, saved + s.h_off[layers], s.w[layers], B, 1, s.w[layers], dw[layers],
-                               dbias[layers], k.wgrad_ws, k.wgrad_bytes, stream));
+    if (params)
+      HIVT_TRY(hivt_linear_wgrad(g_scores, 1, saved + s.h_off[layers], s.w[layers], B, 1, s.w[layers], dw[layers],
+                                 dbias[layers], k.wgrad_ws, k.wgrad_bytes, stream));
     // dz_L = (g w_o) * c_L
     float* dz = k.a;
     float* other = k.b;
@@ -357,8 +369,9 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
     for (int l = layers; l >= 1; --l) {
       const float* h_prev = l > 1 ? saved + s.h_off[l - 1] : x;
       const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : x_ld;
-      HIVT_TRY(hivt_linear_wgrad(dz, s.w[l], h_prev, h_prev_ld, B, s.w[l], s.w[l - 1], dw[l - 1], dbias[l - 1],
-                                 k.wgrad_ws, k.wgrad_bytes, stream));
+      if (params)
+        HIVT_TRY(hivt_linear_wgrad(dz, s.w[l], h_prev, h_prev_ld, B, s.w[l], s.w[l - 1], dw[l - 1], dbias[l - 1],
+                                   k.wgrad_ws, k.wgrad_bytes, stream));
       if (l > 1 || dx != nullptr) {
         float* dh = (l == 1) ? dx : other;
         HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], dh, s.w[l - 1], stream));

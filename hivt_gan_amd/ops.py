@@ -881,6 +881,15 @@ class _Critic(torch.autograd.Function):
         b = x2.shape[0]
         dev = x2.device
         widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
+        if not any(ctx.needs_input_grad[2:]):  # frozen critic (the generator's pass): data gradient only
+            dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            if dx is not None:
+                ws = _workspace(_lib.query("hivt_critic_workspace_bytes", b, layers, tuple(widths_list)), dev)
+                gs = g_scores.contiguous() if g_scores is not None else None
+                _lib.call("hivt_critic_bwd", _p(gs), None, _p(x2), x2.stride(0) if b > 0 else widths_list[0], b, layers,
+                          widths, _ptr_array(weights), neg_slope, dropout_p, _p(saved), None, None, _p(dx), _p(ws),
+                          ws.numel(), _stream(x2))
+            return (dx.view(x_shape) if dx is not None else None, None, *([None] * (2 * len(weights))))
         dws = [torch.empty_like(w) for w in weights]
         dbs = [torch.empty(s, dtype=torch.float32, device=dev) for s in bias_shapes]
         dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None

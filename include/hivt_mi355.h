@@ -400,7 +400,9 @@ int hivt_critic_fwd(const float* x, int64_t x_ld, int64_t B, int32_t layers, con
  * [B] (or NULL) with respect to every weight (dw[l], same shapes as w[l]) and bias, and optionally the
  * input (dx float [B, widths[0]] contiguous, from the score path only: the factors c_l are constants).
  * The grad_norm2 path is the second chain e_0 = 2 g_norm2 g, dW_l += G_l^T e_{l-1},
- * e_l = (e_{l-1} W_l^T) * c_l, dw_o += colsum(e_L). */
+ * e_l = (e_{l-1} W_l^T) * c_l, dw_o += colsum(e_L).
+ * dw = dbias = NULL (with g_norm2 = NULL and dx given): the parameters are frozen -- the generator's pass
+ * through the critics (models/hivt.py:317-327) -- and only dx is computed. */
 int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x, int64_t x_ld, int64_t B,
                     int32_t layers, const int32_t* widths, const float* const* w, float neg_slope, float dropout_p,
                     const float* saved, float* const* dw, float* const* dbias, float* dx, void* workspace,
