@@ -625,7 +625,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int relu, int64_t M, int N, int vec, float* __restrict__ dz,
-                                                     int64_t dz_ld, float* __restrict__ partial /*[grid][2][N]*/) {
+                                                     int64_t dz_ld, float* __restrict__ partial /*[grid][2][N]*/,
+                                                     const float* __restrict__ add, int64_t add_ld) {
   __shared__ float red[4][2][64 * NPL];
   constexpr int U = 2;  // rows in flight per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -694,6 +695,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       float o[NPL];
 #pragma unroll
       for (int j = 0; j < NPL; ++j) o[j] = rstd[u] * (gg[u][j] - s1[u] - xh[u][j] * s2[u]);
+      if (add != nullptr) {  // gradient arriving at the un-normalised input by another route (a residual branch)
+#pragma unroll
+        for (int j = 0; j < NPL; ++j)
+          if (c0 + j < N) o[j] += add[r * add_ld + c0 + j];
+      }
       if (NPL == 2 && full) {
         *reinterpret_cast<float2*>(dz + r * dz_ld + c0) = make_float2(o[0], o[NPL - 1]);
       } else {
@@ -1058,9 +1064,9 @@ extern "C" size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N) {
 }
 
 extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
-                           const float* gamma, const float* beta, int relu, int64_t M, int32_t N, float* dz,
-                           int64_t dz_ld, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                           hivt_stream_t stream) {
+                           const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                           int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, hivt_stream_t stream) {
   const char* what = "hivt_ln_bwd";
   HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128, HIVT_ERR_ARG, "%s: N must be in [1,128] (N=%d)", what, N);
   HIVT_REQUIRE(dgamma && dbeta, HIVT_ERR_ARG, "%s: null gradient output", what);
@@ -1081,10 +1087,10 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
   const int vec = (al8(dy) && al8(z) && al8(dz) && dy_ld % 2 == 0 && z_ld % 2 == 0 && dz_ld % 2 == 0) ? 1 : 0;
   if (N <= 64)
     hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
-                       beta, relu, M, N, vec, dz, dz_ld, partial);
+                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
-                       beta, relu, M, N, vec, dz, dz_ld, partial);
+                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
   HIVT_CHECK_LAUNCH(what);
   // partial is [blocks][2][N]: one reduction over the 2N columns, first half -> dgamma, second -> dbeta
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((2 * N + 63) / 64)), dim3(256), 0, s, partial, (int)blocks,

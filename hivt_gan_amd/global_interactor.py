@@ -50,8 +50,10 @@ class GlobalInteractorLayer(nn.Module):
             edges = _edge_set_from_coo(edge_index, edge_attr.new_zeros(edge_attr.shape[0], 2), x.shape[0], x.shape[0])
             edges.src = edges.coo_src.index_select(0, edges.perm.long())
             edge_attr = edge_attr.index_select(0, edges.perm.long())
-        x = self._mha_block(ops.layer_norm(x, self.norm1), edges, edge_attr, residual=x)
-        return self._ff_block(ops.layer_norm(x, self.norm2), residual=x)
+        normed, x = ops.layer_norm_residual(x, self.norm1)
+        x = self._mha_block(normed, edges, edge_attr, residual=x)
+        normed, x = ops.layer_norm_residual(x, self.norm2)
+        return self._ff_block(normed, residual=x)
 
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor,
                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -196,8 +196,10 @@ class AAEncoder(_EdgeAttentionBase):
         if edges is None:
             edges = _edge_set_from_coo(edge_index, edge_attr, x.shape[0], x.shape[0])
         # the residual additions are part of the last launch of each block
-        center = self._mha_block(ops.layer_norm(center, self.norm1), x, edges, rotate_mat, rot_mod, residual=center)
-        return self._ff_block(ops.layer_norm(center, self.norm2), residual=center)
+        normed, center = ops.layer_norm_residual(center, self.norm1)
+        center = self._mha_block(normed, x, edges, rotate_mat, rot_mod, residual=center)
+        normed, center = ops.layer_norm_residual(center, self.norm2)
+        return self._ff_block(normed, residual=center)
 
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
                    rot_mod: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -229,9 +231,10 @@ class ALEncoder(_EdgeAttentionBase):
             edges = _edge_set_from_coo(edge_index, edge_attr, x_lane.shape[0], x_actor.shape[0])
         # one code per lane for the three categorical attributes, one table row per code
         code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
-        x_actor = self._mha_block(ops.layer_norm(x_actor, self.norm1), x_lane, edges, code, rotate_mat,
-                                  residual=x_actor)
-        return self._ff_block(ops.layer_norm(x_actor, self.norm2), residual=x_actor)
+        normed, x_actor = ops.layer_norm_residual(x_actor, self.norm1)
+        x_actor = self._mha_block(normed, x_lane, edges, code, rotate_mat, residual=x_actor)
+        normed, x_actor = ops.layer_norm_residual(x_actor, self.norm2)
+        return self._ff_block(normed, residual=x_actor)
 
     def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
                    rotate_mat: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -291,8 +294,10 @@ class TemporalEncoderLayer(nn.Module):
 
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
-        x = self._sa_block(ops.layer_norm(src, self.norm1), src)
-        return self._ff(ops.layer_norm(x, self.norm2), x)
+        normed, src = ops.layer_norm_residual(src, self.norm1)
+        x = self._sa_block(normed, src)
+        normed, x = ops.layer_norm_residual(x, self.norm2)
+        return self._ff(normed, x)
 
     def forward_last(self, src: torch.Tensor) -> torch.Tensor:
         """Row ``[-1]`` of ``forward(src)`` ([N, D]) without computing the other rows.  The last position
@@ -323,7 +328,8 @@ class TemporalEncoderLayer(nn.Module):
         o = (prob.unsqueeze(-1) * kv[:, :, 1]).sum(dim=0).reshape(N, D)
         x = lin(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p, training=self.training,
                 residual=src[-1])
-        h = lin(ops.layer_norm(x, self.norm2), self.linear1.weight, self.linear1.bias, relu=True,
+        normed, x = ops.layer_norm_residual(x, self.norm2)
+        h = lin(normed, self.linear1.weight, self.linear1.bias, relu=True,
                 dropout_p=self.dropout.p, training=self.training)
         return lin(h, self.linear2.weight, self.linear2.bias, dropout_p=self.dropout2.p, training=self.training,
                    residual=x)

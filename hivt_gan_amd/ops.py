@@ -532,7 +532,7 @@ class _FusedLinear(torch.autograd.Function):
             dbeta = torch.empty(n, dtype=torch.float32, device=dev)
             ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
             _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), n, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
-                      _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+                      None, 0, _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
         elif dropout_p > 0.0:
             dz = torch.empty(m, n, dtype=torch.float32, device=dev)
             _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), _p(y_relu), n, int(relu), dropout_p, seed,
@@ -567,6 +567,10 @@ class _FusedLinear(torch.autograd.Function):
 
 
 class _LayerNorm(torch.autograd.Function):
+    """``(y, x_again)``: the normalised rows and the input handed back as a second output.  A pre-norm
+    block ``x + block(norm(x))`` takes its residual operand from ``x_again``; autograd then delivers
+    the gradients of both routes to ONE backward call, which sums them inside the LayerNorm-backward
+    kernel instead of in a separate pass over the tensor."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -581,21 +585,26 @@ class _LayerNorm(torch.autograd.Function):
                   _stream(x))
         ctx.save_for_backward(x2, stats, gamma_c, beta_c)
         ctx.lead = tuple(lead)
-        return y.view(*lead, n)
+        ctx.set_materialize_grads(False)
+        return y.view(*lead, n), x.view_as(x)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres):
         x2, stats, gamma, beta = ctx.saved_tensors
         m, n = x2.shape
         dev = x2.device
+        if dy is None:  # only the pass-through output was used
+            return dres, None, None, None
         dy2 = _rows2(dy)
+        add2 = _rows2(dres) if dres is not None else None
         dx = torch.empty(m, n, dtype=torch.float32, device=dev)
         dgamma = torch.empty(n, dtype=torch.float32, device=dev)
         dbeta = torch.empty(n, dtype=torch.float32, device=dev)
         ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
         _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, n,
-                  _p(dx), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _stream(x2))
+                  _p(add2), add2.stride(0) if add2 is not None else 0, _p(dx), n, _p(dgamma), _p(dbeta), _p(ws),
+                  ws.numel(), _stream(x2))
         return dx.view(*ctx.lead, n), dgamma, dbeta, None
 
 
@@ -604,6 +613,15 @@ def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
     and CPU tensors go to the framework's implementation."""
     if not x.is_cuda or x.shape[-1] > 128 or x.dtype != torch.float32 or x.numel() == 0:
         return norm(x)
+    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)[0]
+
+
+def layer_norm_residual(x: torch.Tensor, norm: torch.nn.LayerNorm) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(norm(x), x)`` for a pre-norm block ``x + block(norm(x))``: feed the first to the block and use the
+    second as the residual operand, and the backward pass sums the two gradient routes inside the
+    LayerNorm-backward kernel."""
+    if not x.is_cuda or x.shape[-1] > 128 or x.dtype != torch.float32 or x.numel() == 0:
+        return norm(x), x
     return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
 
 

@@ -257,11 +257,14 @@ int hivt_ln_fwd(const float* x, int64_t x_ld, const float* gamma, const float* b
 size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N);
 
 /* Backward of the LayerNorm (+ReLU when relu != 0) epilogue: from dy, the saved pre-normalisation
- * z and stats, computes dz [M,N], dgamma [N], dbeta [N] (N <= 128). */
+ * z and stats, computes dz [M,N], dgamma [N], dbeta [N] (N <= 128).  add (may be NULL, [M,N] with
+ * row stride add_ld) is added to dz: the gradient that reaches the un-normalised tensor through the
+ * residual connection around the block (x + block(norm(x)), models/local_encoder.py:151-153,266-267;
+ * models/global_interactor.py:104-105), so that the two routes are summed without another pass. */
 int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
-                const float* gamma, const float* beta, int relu, int64_t M, int32_t N, float* dz,
-                int64_t dz_ld, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                hivt_stream_t stream);
+                const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                size_t workspace_bytes, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Temporal encoder attention core (next-row component: TemporalEncoder)

@@ -692,3 +692,31 @@ def test_fused_adversarial_loss_terms_match_framework_ops(B):
     (ref * 0.4).backward()
     assert abs(float(g) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
     assert float((got - s_fake.grad).abs().max()) <= 1e-6 * max(1e-6, float(s_fake.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(300, 128), (21, 50, 64), (5, 100)])
+def test_layer_norm_residual_sums_both_gradient_routes(shape):
+    """x + f(norm(x)) written with ``layer_norm_residual``: outputs and the gradient of x (residual route
+    plus LayerNorm route, summed inside the LayerNorm-backward kernel) against the framework ops."""
+    torch.manual_seed(shape[-1])
+    dev = torch.device("cuda", 0)
+    norm = torch.nn.LayerNorm(shape[-1]).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(*shape, device=dev, requires_grad=True)
+    gy = torch.randn(*shape, device=dev)
+    normed, again = ops.layer_norm_residual(x, norm)
+    out = again * 0.5 + torch.tanh(normed)
+    out.backward(gy)
+    got = [x.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    x.grad = norm.weight.grad = norm.bias.grad = None
+    ref = x * 0.5 + torch.tanh(norm(x))
+    ref.backward(gy)
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    for g, r in zip(got, (x.grad, norm.weight.grad, norm.bias.grad)):
+        assert float((g - r).abs().max()) <= 2e-5 * float(r.abs().max())
+    # either output alone
+    x.grad = None
+    ops.layer_norm_residual(x, norm)[1].mul(2.0).backward(gy)
+    assert torch.equal(x.grad, 2.0 * gy)
