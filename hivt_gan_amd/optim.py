@@ -1,10 +1,12 @@
 """AdamW for GPU parameters with a short host path.
 
 ``torch.optim.AdamW(fused=True)`` rebuilds its tensor lists from ``param_groups`` and ``state`` on every
-call (several hundred microseconds of host time for a few hundred parameters).  ``FusedAdamW`` is the
-same optimizer (same state layout, ``state_dict``, schedulers, ``found_inf`` / ``grad_scale``
-attributes, same multi-tensor kernel) that keeps those lists between calls; whenever the set of
-parameters holding a gradient differs from the cached one it defers to the stock ``step``."""
+call and advances one step counter per parameter (several hundred microseconds of host time and a
+dozen small launches for a few hundred parameters).  ``FusedAdamW`` is the same optimizer (same state
+layout, ``state_dict``, schedulers, ``found_inf`` / ``grad_scale`` attributes, same multi-tensor update
+kernel) that keeps those lists between calls and lets the parameters of a group share ONE step counter
+while their counts agree.  Whenever the set of parameters holding a gradient differs from the cached
+one, and whenever the state is exported or replaced, it returns to the stock layout and ``step``."""
 from __future__ import annotations
 
 import torch
@@ -14,55 +16,108 @@ class FusedAdamW(torch.optim.AdamW):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2) -> None:
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
-        self._lists = None  # per group: (params, exp_avgs, exp_avg_sqs, steps)
+        # per group: (params with a gradient, the rest, exp_avgs, exp_avg_sqs, step list, shared step or None)
+        self._lists = None
+
+    # -- cache management -------------------------------------------------------------------------
+    def _untie(self) -> None:
+        """Back to one step tensor per parameter (the stock layout) and no cached lists."""
+        if self._lists is not None:
+            for params, _, _, _, _, shared in self._lists:
+                if shared is not None:
+                    for p in params:
+                        self.state[p]["step"] = shared.clone()
+        self._lists = None
 
     def _cache(self) -> None:
         lists = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
+            rest = [p for p in group["params"] if p.grad is None]
             states = [self.state[p] for p in params]
             if any(not st for st in states) or group["amsgrad"] or group["maximize"]:
                 self._lists = None
                 return
-            lists.append((params, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
-                          [st["step"] for st in states]))
+            steps = [st["step"] for st in states]
+            shared = None
+            if steps and all(s.is_cuda and s.dim() == 0 for s in steps):
+                first = float(steps[0])  # one read-back, when the cache is (re)built only
+                if all(float(s) == first for s in steps[1:8]) and bool(torch.stack(steps).eq(first).all()):
+                    shared = steps[0].clone()
+                    for st in states:
+                        st["step"] = shared
+                    steps = [shared] * len(states)
+            lists.append((params, rest, [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], steps,
+                          shared))
         self._lists = lists
 
+    def state_dict(self):
+        self._untie()
+        return super().state_dict()
+
     def load_state_dict(self, state_dict) -> None:
-        super().load_state_dict(state_dict)
         self._lists = None
+        super().load_state_dict(state_dict)
+        for st in self.state.values():  # a loaded file may alias the counters of a tied group
+            if "step" in st:
+                st["step"] = st["step"].clone()
 
     def add_param_group(self, param_group) -> None:
+        if getattr(self, "_lists", None) is not None:
+            self._untie()
         super().add_param_group(param_group)
-        self._lists = None
 
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
+    # -- the update ---------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
         lists = self._lists
         if closure is None and lists is not None and len(lists) == len(self.param_groups):
             grads_per_group = []
-            for group, (params, _, _, _) in zip(self.param_groups, lists):
+            for params, rest, _, _, _, _ in lists:
                 grads = [p.grad for p in params]
-                with_grad = sum(p.grad is not None for p in group["params"])
-                if with_grad != len(params) or any(g is None for g in grads):
+                ok = True
+                for g in grads:
+                    if g is None:
+                        ok = False
+                        break
+                if ok:
+                    for p in rest:
+                        if p.grad is not None:
+                            ok = False
+                            break
+                if not ok:
                     grads_per_group = None
                     break
                 grads_per_group.append(grads)
             if grads_per_group is not None:
                 found_inf = getattr(self, "found_inf", None)
                 grad_scale = getattr(self, "grad_scale", None)
-                for group, (params, exp_avgs, exp_avg_sqs, steps), grads in zip(self.param_groups, lists,
-                                                                              grads_per_group):
+                for group, (params, _, exp_avgs, exp_avg_sqs, steps, shared), grads in zip(self.param_groups, lists,
+                                                                                         grads_per_group):
                     if not params:
                         continue
                     beta1, beta2 = group["betas"]
-                    torch._foreach_add_(steps, 1)
+                    if shared is not None:
+                        shared.add_(1)
+                    else:
+                        torch._foreach_add_(steps, 1)
                     torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
                                         lr=group["lr"], beta1=beta1, beta2=beta2, weight_decay=group["weight_decay"],
                                         eps=group["eps"], maximize=False, grad_scale=grad_scale, found_inf=found_inf)
                     if found_inf is not None:  # a skipped update does not count as a step
-                        torch._foreach_sub_(steps, [found_inf] * len(steps))
+                        if shared is not None:
+                            shared.sub_(found_inf.to(shared.dtype).view(()))
+                        else:
+                            torch._foreach_sub_(steps, [found_inf] * len(steps))
                 return None
+        self._untie()
         out = super().step(closure)
         self._cache()
         return out
