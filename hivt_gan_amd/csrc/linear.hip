@@ -150,6 +150,10 @@ struct Tail {
   const uint64_t* seed_ptr = nullptr;  // optional device-side value added to seed
   const float* residual = nullptr;
   int64_t res_ld = 0;
+  // residual_is_mask: the tensor in `residual` is not added; it gates the value instead:
+  // out = residual > 0 ? value * mask_scale : 0 (gradient through a ReLU [+ dropout] whose output it is)
+  bool residual_is_mask = false;
+  float mask_scale = 1.0f;
 };
 
 // DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
@@ -377,8 +381,13 @@ struct Core {
           v1 = uniform01(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
         }
         if (t.residual != nullptr) {
-          v0 += res0[r];
-          v1 += res1[r];
+          if (t.residual_is_mask) {
+            v0 = res0[r] > 0.0f ? v0 * t.mask_scale : 0.0f;
+            v1 = res1[r] > 0.0f ? v1 * t.mask_scale : 0.0f;
+          } else {
+            v0 += res0[r];
+            v1 += res1[r];
+          }
         }
         if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
         if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
@@ -510,6 +519,9 @@ struct BwdDataArgs {
   float* dx;
   int64_t dx_ld;
   int32_t M, K;
+  const float* mask;  // optional [M,K]: dx = mask > 0 ? dx * mask_scale : 0
+  int64_t mask_ld;
+  float mask_scale;
 };
 
 template <int BM, int BN, bool VEC, bool DEEP = false>
@@ -519,7 +531,12 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
-  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, Tail{}, make_float2(0.0f, 0.0f));
+  Tail t{};
+  t.residual = a.mask;
+  t.res_ld = a.mask_ld;
+  t.residual_is_mask = true;
+  t.mask_scale = a.mask_scale;
+  C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, t, make_float2(0.0f, 0.0f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -975,7 +992,8 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
 }
 
 extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
-                                    int32_t N, int32_t K, float* dx, int64_t dx_ld, hivt_stream_t stream) {
+                                    int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
+                                    float* dx, int64_t dx_ld, hivt_stream_t stream) {
   const char* what = "hivt_linear_bwd_data";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   if (M == 0) return HIVT_OK;
@@ -984,6 +1002,7 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   a.dy = make_operand(dy, dy_ld, (int32_t)M, N, true);
   a.w = make_operand(w, w_ld, K, N, false);  // W[n][k]: reduction index n is the row of the memory image
   a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K;
+  a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
   if (K <= 64) {

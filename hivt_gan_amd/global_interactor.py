@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from . import ops
 from .embedding import MultipleInputEmbedding, SingleInputEmbedding, init_weights
-from .local_encoder import _edge_set_from_coo, _feed_forward, _fused_linear, _linear, build_edge_plan
+from .local_encoder import (_edge_set_from_coo, _feed_forward, _fused_linear, _linear, _pre_norm_ffn,
+                            build_edge_plan)
 from .ops import EdgeSet
 
 
@@ -52,8 +53,7 @@ class GlobalInteractorLayer(nn.Module):
             edge_attr = edge_attr.index_select(0, edges.perm.long())
         normed, x = ops.layer_norm_residual(x, self.norm1)
         x = self._mha_block(normed, edges, edge_attr, residual=x)
-        normed, x = ops.layer_norm_residual(x, self.norm2)
-        return self._ff_block(normed, residual=x)
+        return _pre_norm_ffn(x, self.norm2, self.mlp)
 
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor,
                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -119,6 +119,15 @@ def _feed_forward(mlp: nn.Sequential, x: torch.Tensor, residual: Optional[torch.
     return _linear(_linear(x, mlp[0], relu=True, drop=mlp[2]), mlp[3], drop=mlp[4], residual=residual)
 
 
+def _pre_norm_ffn(x: torch.Tensor, norm: nn.LayerNorm, mlp: nn.Sequential) -> torch.Tensor:
+    """``x + mlp(norm(x))`` for the Linear, ReLU, Dropout, Linear, Dropout stacks: one autograd node on
+    the GPU, framework ops elsewhere."""
+    if ops.pre_norm_feed_forward_supported(x, mlp[0], mlp[3]):
+        return ops.pre_norm_feed_forward(x, norm, mlp[0], mlp[2].p, mlp[3], mlp[4].p, mlp[2].training)
+    normed, x = ops.layer_norm_residual(x, norm)
+    return _feed_forward(mlp, normed, x)
+
+
 class _EdgeAttentionBase(nn.Module):
     """Parameters and the dense tail shared by AAEncoder and ALEncoder."""
 
@@ -198,8 +207,7 @@ class AAEncoder(_EdgeAttentionBase):
         # the residual additions are part of the last launch of each block
         normed, center = ops.layer_norm_residual(center, self.norm1)
         center = self._mha_block(normed, x, edges, rotate_mat, rot_mod, residual=center)
-        normed, center = ops.layer_norm_residual(center, self.norm2)
-        return self._ff_block(normed, residual=center)
+        return _pre_norm_ffn(center, self.norm2, self.mlp)
 
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
                    rot_mod: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -233,8 +241,7 @@ class ALEncoder(_EdgeAttentionBase):
         code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
         normed, x_actor = ops.layer_norm_residual(x_actor, self.norm1)
         x_actor = self._mha_block(normed, x_lane, edges, code, rotate_mat, residual=x_actor)
-        normed, x_actor = ops.layer_norm_residual(x_actor, self.norm2)
-        return self._ff_block(normed, residual=x_actor)
+        return _pre_norm_ffn(x_actor, self.norm2, self.mlp)
 
     def _mha_block(self, x_actor: torch.Tensor, x_lane: torch.Tensor, edges: EdgeSet, lane_code: torch.Tensor,
                    rotate_mat: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -292,12 +299,19 @@ class TemporalEncoderLayer(nn.Module):
                                     training=self.training, residual=residual)
         return residual + self.dropout2(self.linear2(self.dropout(F.relu(self.linear1(x)))))
 
+    def _ff_residual(self, x: torch.Tensor) -> torch.Tensor:
+        # x + _ff_block(norm2(x)) (``models/local_encoder.py:267``)
+        if ops.pre_norm_feed_forward_supported(x, self.linear1, self.linear2):
+            return ops.pre_norm_feed_forward(x, self.norm2, self.linear1, self.dropout.p, self.linear2, self.dropout2.p,
+                                             self.training)
+        normed, x = ops.layer_norm_residual(x, self.norm2)
+        return self._ff(normed, x)
+
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
         normed, src = ops.layer_norm_residual(src, self.norm1)
         x = self._sa_block(normed, src)
-        normed, x = ops.layer_norm_residual(x, self.norm2)
-        return self._ff(normed, x)
+        return self._ff_residual(x)
 
     def forward_last(self, src: torch.Tensor) -> torch.Tensor:
         """Row ``[-1]`` of ``forward(src)`` ([N, D]) without computing the other rows.  The last position
@@ -328,11 +342,7 @@ class TemporalEncoderLayer(nn.Module):
         o = (prob.unsqueeze(-1) * kv[:, :, 1]).sum(dim=0).reshape(N, D)
         x = lin(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p, training=self.training,
                 residual=src[-1])
-        normed, x = ops.layer_norm_residual(x, self.norm2)
-        h = lin(normed, self.linear1.weight, self.linear1.bias, relu=True,
-                dropout_p=self.dropout.p, training=self.training)
-        return lin(h, self.linear2.weight, self.linear2.bias, dropout_p=self.dropout2.p, training=self.training,
-                   residual=x)
+        return self._ff_residual(x)
 
 
 class _EncoderStack(nn.Module):

@@ -544,7 +544,8 @@ class _FusedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(m, k, dtype=torch.float32, device=dev)
-            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, _p(dx), k, s)
+            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, _p(dx),
+                      k, s)
             dx = dx.view(*lead, k)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty(n, k, dtype=torch.float32, device=dev)
@@ -1000,3 +1001,96 @@ class _WeightedMean(torch.autograd.Function):
 def weighted_mean(s: torch.Tensor, w: torch.Tensor, count: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     """``scale * sum(w * s) / count`` as a 0-d tensor (``count``: device scalar)."""
     return _WeightedMean.apply(s, w, count, scale)
+
+
+# --------------------------------------------------------------------------------------------
+# Pre-norm feed-forward block as ONE autograd node
+# --------------------------------------------------------------------------------------------
+class _PreNormFeedForward(torch.autograd.Function):
+    """``x + drop2(lin2(drop1(relu(lin1(norm(x))))))`` (``models/local_encoder.py:153,201-202,267,278-280``;
+    ``models/global_interactor.py:105``): three launches forward; backward carries the gradient through
+    the ReLU / first dropout inside the second Linear's data-gradient product and sums the residual route
+    inside the LayerNorm backward, so no [M, 4D] or [M, D] tensor is passed over on its own."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, p1, p2, seed1, seed2):
+        _need_gpu(x, w1, w2)
+        lead = x.shape[:-1]
+        x2 = _rows2(x)
+        m, d = x2.shape
+        hdim = w1.shape[0]
+        if w1.shape[1] != d or w2.shape != (d, hdim):
+            raise ValueError(f"feed-forward weights {tuple(w1.shape)}, {tuple(w2.shape)} do not fit rows of width {d}")
+        dev = x.device
+        gamma_c, beta_c = gamma.contiguous(), beta.contiguous()
+        w1c, w2c, b1c, b2c = _rows2(w1), _rows2(w2), b1.contiguous(), b2.contiguous()
+        s = _stream(x)
+        xn = torch.empty(m, d, dtype=torch.float32, device=dev)
+        stats = torch.empty(m, 2, dtype=torch.float32, device=dev)
+        h = torch.empty(m, hdim, dtype=torch.float32, device=dev)
+        y = torch.empty(m, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_ln_fwd", _p(x2), x2.stride(0), _p(gamma_c), _p(beta_c), float(eps), m, d, _p(xn), d, _p(stats), s)
+        _lib.call("hivt_linear_fwd", _p(xn), d, _p(w1c), w1c.stride(0), _p(b1c), None, 0, None, 0, None, None, 0.0,
+                  EPI_RELU, 1.0, float(p1), int(seed1), _seed_ptr(p1), None, 0, m, hdim, d, _p(h), hdim, None, 0, None, s)
+        _lib.call("hivt_linear_fwd", _p(h), hdim, _p(w2c), w2c.stride(0), _p(b2c), None, 0, None, 0, None, None, 0.0,
+                  EPI_NONE, 1.0, float(p2), int(seed2), _seed_ptr(p2), _p(x2), x2.stride(0), m, d, hdim, _p(y), d, None,
+                  0, None, s)
+        ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, h, w1c, w2c, DEVICE_SEED if p2 > 0.0 else None)
+        ctx.cfg = (tuple(lead), float(p1), float(p2), int(seed2))
+        return y.view(*lead, d)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, stats, gamma, beta, xn, h, w1, w2, seed_dev = ctx.saved_tensors
+        lead, p1, p2, seed2 = ctx.cfg
+        m, d = x2.shape
+        hdim = w1.shape[0]
+        dev = x2.device
+        s = _stream(x2)
+        dy2 = _rows2(dy)
+        if p2 > 0.0:
+            dz2 = torch.empty(m, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), None, 0, 0, p2, seed2, _p(seed_dev), m, d, _p(dz2), d, s)
+        else:
+            dz2 = dy2
+        # second Linear: weight gradient, then the data gradient gated by the ReLU / dropout of its input
+        dw2 = torch.empty(d, hdim, dtype=torch.float32, device=dev)
+        db2 = torch.empty(d, dtype=torch.float32, device=dev)
+        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", m, d, hdim),
+                            _lib.query("hivt_linear_wgrad_workspace_bytes", m, hdim, d),
+                            _lib.query("hivt_ln_bwd_workspace_bytes", m, d)), dev)
+        _lib.call("hivt_linear_wgrad", _p(dz2), dz2.stride(0), _p(h), hdim, m, d, hdim, _p(dw2), _p(db2), _p(ws),
+                  ws.numel(), s)
+        dz1 = torch.empty(m, hdim, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
+                  1.0 / (1.0 - p1), _p(dz1), hdim, s)
+        # first Linear
+        dw1 = torch.empty(hdim, d, dtype=torch.float32, device=dev)
+        db1 = torch.empty(hdim, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_wgrad", _p(dz1), hdim, _p(xn), d, m, hdim, d, _p(dw1), _p(db1), _p(ws), ws.numel(), s)
+        dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, _p(dxn), d, s)
+        # LayerNorm, plus the residual route's gradient (dy itself)
+        dx = torch.empty(m, d, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(d, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_ln_bwd", _p(dxn), d, _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, d, _p(dy2),
+                  dy2.stride(0), _p(dx), d, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+        return dx.view(*lead, d), dgamma, dbeta, None, dw1, db1, dw2, db2, None, None, None, None
+
+
+def pre_norm_feed_forward(x: torch.Tensor, norm: torch.nn.LayerNorm, lin1: torch.nn.Linear, p1: float,
+                          lin2: torch.nn.Linear, p2: float, training: bool) -> torch.Tensor:
+    """``x + dropout_p2(lin2(dropout_p1(relu(lin1(norm(x))))))`` as one autograd node (GPU tensors, rows of
+    at most 128 columns, both Linears with a bias)."""
+    p1 = float(p1) if training else 0.0
+    p2 = float(p2) if training else 0.0
+    return _PreNormFeedForward.apply(x, norm.weight, norm.bias, norm.eps, lin1.weight, lin1.bias, lin2.weight,
+                                     lin2.bias, p1, p2, _fresh_seed() if p1 > 0.0 else 0,
+                                     _fresh_seed() if p2 > 0.0 else 0)
+
+
+def pre_norm_feed_forward_supported(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 128 and x.numel() > 0
+            and lin1.bias is not None and lin2.bias is not None)

@@ -233,9 +233,14 @@ int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_l
                      uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz, int64_t dz_ld,
                      hivt_stream_t stream);
 
-/* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue). */
+/* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue).
+ * mask (may be NULL, [M,K] with row stride mask_ld): x was itself the output of a ReLU [+ dropout] epilogue,
+ * and the gradient is carried through it in the same pass: dx = mask > 0 ? dx * mask_scale : 0, with
+ * mask = that output and mask_scale = 1 / (1 - its dropout probability) -- the step from the second to the
+ * first Linear of a feed-forward block (models/local_encoder.py:117-122,279). */
 int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
-                         int32_t K, float* dx, int64_t dx_ld, hivt_stream_t stream);
+                         int32_t K, const float* mask, int64_t mask_ld, float mask_scale, float* dx, int64_t dx_ld,
+                         hivt_stream_t stream);
 
 /* Workspace for hivt_linear_wgrad. */
 size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);

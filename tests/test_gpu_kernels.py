@@ -720,3 +720,47 @@ def test_layer_norm_residual_sums_both_gradient_routes(shape):
     x.grad = None
     ops.layer_norm_residual(x, norm)[1].mul(2.0).backward(gy)
     assert torch.equal(x.grad, 2.0 * gy)
+
+
+@pytest.mark.parametrize("M,D,p", [(700, 128, 0.0), (2623, 64, 0.0), (3000, 128, 0.1)])
+def test_pre_norm_feed_forward_block(M, D, p):
+    """x + drop(lin2(drop(relu(lin1(norm(x)))))) as one autograd node: output and all seven gradients
+    against the framework ops; with dropout active, against the framework ops fed the kernel's own masks
+    (read back from the block's saved activations)."""
+    torch.manual_seed(M + D)
+    dev = torch.device("cuda", 0)
+    norm = torch.nn.LayerNorm(D).to(dev)
+    lin1, lin2 = torch.nn.Linear(D, 4 * D).to(dev), torch.nn.Linear(4 * D, D).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.2, 0.2)
+    params = [norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+    x = torch.randn(M, D, device=dev, requires_grad=True)
+    gy = torch.randn(M, D, device=dev)
+    assert ops.pre_norm_feed_forward_supported(x, lin1, lin2)
+    torch.manual_seed(99)
+    y = ops.pre_norm_feed_forward(x, norm, lin1, p, lin2, p, True)
+    h_saved = y.grad_fn.saved_tensors[5].clone()  # hidden activation kept by the node
+    y.backward(gy)
+    got = [x.grad.clone()] + [q.grad.clone() for q in params]
+    x.grad = None
+    for q in params:
+        q.grad = None
+    z1 = lin1(norm(x))
+    if p == 0.0:
+        hidden = torch.relu(z1)
+        ref = x + lin2(hidden)
+    else:
+        # masks of the kernel run: from the saved hidden activation, and from the output
+        # active-and-kept units are the positive entries of the saved activation (the ReLU decision is
+        # taken from the kernel too: a pre-activation within rounding of zero may fall on either side)
+        hidden = z1 * (h_saved > 0) / (1.0 - p)
+        pre = lin2(hidden)
+        keep2 = ((y.detach() - x.detach()).abs() > 0) | (pre.detach() == 0)
+        frac = 1.0 - float(keep2.float().mean())
+        assert abs(frac - p) < 0.01 and abs(1.0 - float(((h_saved > 0) | (z1.detach() <= 0)).float().mean()) - p / 2) < 0.02
+        ref = x + pre * keep2 / (1.0 - p)
+    ref.backward(gy)
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    for g, r, name in zip(got, [x.grad] + [q.grad for q in params], ["x", "gamma", "beta", "w1", "b1", "w2", "b2"]):
+        assert float((g - r).abs().max()) <= 3e-5 * float(r.abs().max()), name
