@@ -309,8 +309,13 @@ class TemporalEncoderLayer(nn.Module):
 
     def forward(self, src: torch.Tensor, src_mask: Optional[torch.Tensor] = None,
                 src_key_padding_mask: Optional[torch.Tensor] = None, is_causal: bool = True) -> torch.Tensor:
-        normed, src = ops.layer_norm_residual(src, self.norm1)
-        x = self._sa_block(normed, src)
+        S, _, D = src.shape
+        if src.is_cuda and src.dtype == torch.float32 and D <= 128 and src.numel() > 0 \
+                and ops.temporal_attention_supported(S, D, self.self_attn.num_heads):
+            x = ops.pre_norm_temporal_attention(src, self.norm1, self.self_attn, self.dropout1.p, self.training)
+        else:
+            normed, src = ops.layer_norm_residual(src, self.norm1)
+            x = self._sa_block(normed, src)
         return self._ff_residual(x)
 
     def forward_last(self, src: torch.Tensor) -> torch.Tensor:

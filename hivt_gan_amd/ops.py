@@ -1094,3 +1094,94 @@ def pre_norm_feed_forward(x: torch.Tensor, norm: torch.nn.LayerNorm, lin1: torch
 def pre_norm_feed_forward_supported(x: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] <= 128 and x.numel() > 0
             and lin1.bias is not None and lin2.bias is not None)
+
+
+# --------------------------------------------------------------------------------------------
+# Pre-norm causal self-attention block of the temporal encoder as ONE autograd node
+# --------------------------------------------------------------------------------------------
+class _PreNormTemporalAttention(torch.autograd.Function):
+    """``x + drop(out_proj(causal_attention(in_proj(norm(x)))))`` for x [S, N, D]
+    (``models/local_encoder.py:266,269-276``): LayerNorm, the fused q|k|v projection, the attention kernel
+    and the output projection with dropout and residual, four launches forward and one node in the graph."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w_in, b_in, w_out, b_out, num_heads, p_attn, p_out, seed_attn, seed_out):
+        _need_gpu(x, w_in, w_out)
+        s_len, n, d = x.shape
+        x2 = _rows2(x)
+        m = x2.shape[0]
+        dev = x.device
+        st = _stream(x)
+        gamma_c, beta_c = gamma.contiguous(), beta.contiguous()
+        w_in_c, w_out_c, b_in_c, b_out_c = _rows2(w_in), _rows2(w_out), b_in.contiguous(), b_out.contiguous()
+        xn = torch.empty(m, d, dtype=torch.float32, device=dev)
+        stats = torch.empty(m, 2, dtype=torch.float32, device=dev)
+        qkv = torch.empty(m, 3 * d, dtype=torch.float32, device=dev)
+        o = torch.empty(m, d, dtype=torch.float32, device=dev)
+        lse = torch.empty(n, num_heads, s_len, dtype=torch.float32, device=dev)
+        y = torch.empty(m, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_ln_fwd", _p(x2), x2.stride(0), _p(gamma_c), _p(beta_c), float(eps), m, d, _p(xn), d, _p(stats), st)
+        _lib.call("hivt_linear_fwd", _p(xn), d, _p(w_in_c), w_in_c.stride(0), _p(b_in_c), None, 0, None, 0, None, None,
+                  0.0, EPI_NONE, 1.0, 0.0, 0, None, None, 0, m, 3 * d, d, _p(qkv), 3 * d, None, 0, None, st)
+        _lib.call("hivt_temporal_attn_fwd", _p(qkv), s_len, n, d, num_heads, float(p_attn), int(seed_attn),
+                  _seed_ptr(p_attn), _p(o), _p(lse), st)
+        _lib.call("hivt_linear_fwd", _p(o), d, _p(w_out_c), w_out_c.stride(0), _p(b_out_c), None, 0, None, 0, None, None,
+                  0.0, EPI_NONE, 1.0, float(p_out), int(seed_out), _seed_ptr(p_out), _p(x2), x2.stride(0), m, d, d,
+                  _p(y), d, None, 0, None, st)
+        ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, qkv, o, lse, w_in_c, w_out_c,
+                              DEVICE_SEED if (p_attn > 0.0 or p_out > 0.0) else None)
+        ctx.cfg = (s_len, n, int(num_heads), float(p_attn), float(p_out), int(seed_attn), int(seed_out))
+        return y.view(s_len, n, d)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, stats, gamma, beta, xn, qkv, o, lse, w_in, w_out, seed_dev = ctx.saved_tensors
+        s_len, n, num_heads, p_attn, p_out, seed_attn, seed_out = ctx.cfg
+        m, d = x2.shape
+        dev = x2.device
+        st = _stream(x2)
+        dy2 = _rows2(dy)
+        if p_out > 0.0:
+            dz = torch.empty(m, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), None, 0, 0, p_out, seed_out, _p(seed_dev), m, d, _p(dz),
+                      d, st)
+        else:
+            dz = dy2
+        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", m, d, d),
+                            _lib.query("hivt_linear_wgrad_workspace_bytes", m, 3 * d, d),
+                            _lib.query("hivt_ln_bwd_workspace_bytes", m, d)), dev)
+        dw_out = torch.empty(d, d, dtype=torch.float32, device=dev)
+        db_out = torch.empty(d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(o), d, m, d, d, _p(dw_out), _p(db_out), _p(ws),
+                  ws.numel(), st)
+        do = torch.empty(m, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, _p(do),
+                  d, st)
+        dqkv = torch.empty(m, 3 * d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_temporal_attn_bwd", _p(do), _p(qkv), _p(o), _p(lse), s_len, n, d, num_heads, p_attn, seed_attn,
+                  _p(seed_dev), _p(dqkv), st)
+        dw_in = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
+        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_wgrad", _p(dqkv), 3 * d, _p(xn), d, m, 3 * d, d, _p(dw_in), _p(db_in), _p(ws), ws.numel(),
+                  st)
+        dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, _p(dxn),
+                  d, st)
+        dx = torch.empty(m, d, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(d, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_ln_bwd", _p(dxn), d, _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, d, _p(dy2),
+                  dy2.stride(0), _p(dx), d, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), st)
+        return (dx.view(s_len, n, d), dgamma, dbeta, None, dw_in, db_in, dw_out, db_out, None, None, None, None, None)
+
+
+def pre_norm_temporal_attention(x: torch.Tensor, norm: torch.nn.LayerNorm, mha: torch.nn.MultiheadAttention,
+                                p_out: float, training: bool) -> torch.Tensor:
+    """``x + dropout_p_out(mha.out_proj(causal self-attention(mha.in_proj(norm(x)))))`` over the first
+    axis of x [S, N, D] as one autograd node (needs ``temporal_attention_supported`` and D <= 128)."""
+    p_attn = float(mha.dropout) if training else 0.0
+    p_out = float(p_out) if training else 0.0
+    return _PreNormTemporalAttention.apply(x, norm.weight, norm.bias, norm.eps, mha.in_proj_weight, mha.in_proj_bias,
+                                           mha.out_proj.weight, mha.out_proj.bias, mha.num_heads, p_attn, p_out,
+                                           _fresh_seed() if p_attn > 0.0 else 0, _fresh_seed() if p_out > 0.0 else 0)
