@@ -48,7 +48,7 @@ SIGNATURES = {
     "hivt_rowsum_by_code_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_rowsum_by_code": (c_int, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "hivt_linear_bwd_data": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_float, _P,
-                                     c_int64, _P]),
+                                     c_int64, _P, c_int64, _P]),
     "hivt_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_linear_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "hivt_ln_fwd": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int32, _P, c_int64, _P, _P]),

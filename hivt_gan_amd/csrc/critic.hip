@@ -302,7 +302,7 @@ extern "C" int hivt_critic_fwd(const float* x, int64_t x_ld, int64_t B, int32_t 
   for (int l = layers; l >= 1; --l) {
     float* g_prev = l > 1 ? saved + s.g_off[l - 1] : saved + s.g0_off;
     HIVT_TRY(hivt_linear_bwd_data(saved + s.g_off[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0,
-                                  1.0f, g_prev, s.w[l - 1], stream));
+                                  1.0f, nullptr, 0, g_prev, s.w[l - 1], stream));
     if (l > 1) {
       hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,
                          (const float*)g_prev, (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l - 1],
@@ -374,7 +374,7 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
                                    k.wgrad_ws, k.wgrad_bytes, stream));
       if (l > 1 || dx != nullptr) {
         float* dh = (l == 1) ? dx : other;
-        HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f, dh,
+        HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f, nullptr, 0, dh,
                                       s.w[l - 1], stream));
         if (l > 1) {
           hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,

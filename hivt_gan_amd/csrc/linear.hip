@@ -522,6 +522,8 @@ struct BwdDataArgs {
   const float* mask;  // optional [M,K]: dx = mask > 0 ? dx * mask_scale : 0
   int64_t mask_ld;
   float mask_scale;
+  const float* add;   // optional [M,K], exclusive with mask: dx += add
+  int64_t add_ld;
 };
 
 template <int BM, int BN, bool VEC, bool DEEP = false>
@@ -532,10 +534,15 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
   Tail t{};
-  t.residual = a.mask;
-  t.res_ld = a.mask_ld;
-  t.residual_is_mask = true;
-  t.mask_scale = a.mask_scale;
+  if (a.mask != nullptr) {
+    t.residual = a.mask;
+    t.res_ld = a.mask_ld;
+    t.residual_is_mask = true;
+    t.mask_scale = a.mask_scale;
+  } else {
+    t.residual = a.add;
+    t.res_ld = a.add_ld;
+  }
   C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, t, make_float2(0.0f, 0.0f));
 }
 
@@ -993,7 +1000,8 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
 
 extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
                                     int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
-                                    float* dx, int64_t dx_ld, hivt_stream_t stream) {
+                                    const float* add, int64_t add_ld, float* dx, int64_t dx_ld,
+                                    hivt_stream_t stream) {
   const char* what = "hivt_linear_bwd_data";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   if (M == 0) return HIVT_OK;
@@ -1002,7 +1010,9 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   a.dy = make_operand(dy, dy_ld, (int32_t)M, N, true);
   a.w = make_operand(w, w_ld, K, N, false);  // W[n][k]: reduction index n is the row of the memory image
   a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K;
+  HIVT_REQUIRE(mask == nullptr || add == nullptr, HIVT_ERR_UNSUPPORTED, "%s: mask and add are exclusive", what);
   a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale;
+  a.add = add; a.add_ld = add_ld;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
   if (K <= 64) {

@@ -65,6 +65,9 @@ class GlobalInteractorLayer(nn.Module):
                            kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
                            perm_by_src=edges.perm_by_src, tag=type(self).__name__,
                            padded=edges.count is not None)
+        if residual is not None:
+            return ops.gated_update_tail(agg, x, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
+                                         self.proj_drop.p, self.proj_drop.training)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(x, self.lin_hh, self.lin_self))
         return _linear(upd, self.out_proj, drop=self.proj_drop, residual=residual)
 

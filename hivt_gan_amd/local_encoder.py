@@ -159,6 +159,9 @@ class _EdgeAttentionBase(nn.Module):
         q = _linear(center, self.lin_q)
         agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
                            tag=type(self).__name__, padded=edges.count is not None)
+        if residual is not None:
+            return ops.gated_update_tail(agg, center, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
+                                         self.proj_drop.p, self.proj_drop.training)
         upd = ops.gated_update(agg, _linear(agg, self.lin_ih), _fused_linear(center, self.lin_hh, self.lin_self))
         return _linear(upd, self.out_proj, drop=self.proj_drop, residual=residual)
 

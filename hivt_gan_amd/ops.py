@@ -544,8 +544,8 @@ class _FusedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(m, k, dtype=torch.float32, device=dev)
-            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, _p(dx),
-                      k, s)
+            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, None, 0,
+                      _p(dx), k, s)
             dx = dx.view(*lead, k)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty(n, k, dtype=torch.float32, device=dev)
@@ -1064,13 +1064,13 @@ class _PreNormFeedForward(torch.autograd.Function):
                   ws.numel(), s)
         dz1 = torch.empty(m, hdim, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
-                  1.0 / (1.0 - p1), _p(dz1), hdim, s)
+                  1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
         # first Linear
         dw1 = torch.empty(hdim, d, dtype=torch.float32, device=dev)
         db1 = torch.empty(hdim, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_wgrad", _p(dz1), hdim, _p(xn), d, m, hdim, d, _p(dw1), _p(db1), _p(ws), ws.numel(), s)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, _p(dxn), d, s)
+        _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0, _p(dxn), d, s)
         # LayerNorm, plus the residual route's gradient (dy itself)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
         dgamma = torch.empty(d, dtype=torch.float32, device=dev)
@@ -1156,8 +1156,8 @@ class _PreNormTemporalAttention(torch.autograd.Function):
         _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(o), d, m, d, d, _p(dw_out), _p(db_out), _p(ws),
                   ws.numel(), st)
         do = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, _p(do),
-                  d, st)
+        _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, None, 0,
+                  _p(do), d, st)
         dqkv = torch.empty(m, 3 * d, dtype=torch.float32, device=dev)
         _lib.call("hivt_temporal_attn_bwd", _p(do), _p(qkv), _p(o), _p(lse), s_len, n, d, num_heads, p_attn, seed_attn,
                   _p(seed_dev), _p(dqkv), st)
@@ -1166,8 +1166,8 @@ class _PreNormTemporalAttention(torch.autograd.Function):
         _lib.call("hivt_linear_wgrad", _p(dqkv), 3 * d, _p(xn), d, m, 3 * d, d, _p(dw_in), _p(db_in), _p(ws), ws.numel(),
                   st)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, _p(dxn),
-                  d, st)
+        _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, None, 0,
+                  _p(dxn), d, st)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
         dgamma = torch.empty(d, dtype=torch.float32, device=dev)
         dbeta = torch.empty(d, dtype=torch.float32, device=dev)
@@ -1185,3 +1185,96 @@ def pre_norm_temporal_attention(x: torch.Tensor, norm: torch.nn.LayerNorm, mha: 
     return _PreNormTemporalAttention.apply(x, norm.weight, norm.bias, norm.eps, mha.in_proj_weight, mha.in_proj_bias,
                                            mha.out_proj.weight, mha.out_proj.bias, mha.num_heads, p_attn, p_out,
                                            _fresh_seed() if p_attn > 0.0 else 0, _fresh_seed() if p_out > 0.0 else 0)
+
+
+# --------------------------------------------------------------------------------------------
+# Gate + update + output projection of an edge-attention block as ONE autograd node
+# --------------------------------------------------------------------------------------------
+class _GatedUpdateTail(torch.autograd.Function):
+    """``res + drop(out_proj(agg + sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg)))``
+    (``models/local_encoder.py:183-188,197-199``; ``models/global_interactor.py:126-131,138-140``) from
+    the aggregated messages ``agg`` and the normalised centre rows ``c``: four launches forward
+    (lin_ih, lin_hh | lin_self as one product, the gate, out_proj with dropout and residual)."""
+
+    @staticmethod
+    def forward(ctx, agg, center, res, w_ih, b_ih, w_hh, b_hh, w_self, b_self, w_out, b_out, p_out, seed_out):
+        _need_gpu(agg, center, res, w_ih, w_out)
+        n, d = agg.shape
+        dev = agg.device
+        st = _stream(agg)
+        agg2, c2, r2 = _rows2(agg), _rows2(center), _rows2(res)
+        w_hs = torch.cat([w_hh, w_self], dim=0)
+        b_hs = torch.cat([b_hh, b_self], dim=0)
+        w_ih_c, w_out_c, b_ih_c, b_out_c = _rows2(w_ih), _rows2(w_out), b_ih.contiguous(), b_out.contiguous()
+        ih = torch.empty(n, d, dtype=torch.float32, device=dev)
+        hs = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)
+        upd = torch.empty(n, d, dtype=torch.float32, device=dev)
+        y = torch.empty(n, d, dtype=torch.float32, device=dev)
+
+        def linear(x, x_ld, w, b, rows_out, out, drop=0.0, seed=0, residual=None, res_ld=0):
+            _lib.call("hivt_linear_fwd", _p(x), x_ld, _p(w), w.stride(0), _p(b), None, 0, None, 0, None, None, 0.0,
+                      EPI_NONE, 1.0, float(drop), int(seed), _seed_ptr(drop), _p(residual), res_ld, n, rows_out, d,
+                      _p(out), rows_out, None, 0, None, st)
+
+        linear(agg2, agg2.stride(0), w_ih_c, b_ih_c, d, ih)
+        linear(c2, c2.stride(0), w_hs, b_hs, 2 * d, hs)
+        _lib.call("hivt_gated_update_fwd", _p(agg2), agg2.stride(0), _p(ih), d, _p(hs), 2 * d, _p(hs, 4 * d), 2 * d, n, d,
+                  _p(upd), st)
+        linear(upd, d, w_out_c, b_out_c, d, y, p_out, seed_out, r2, r2.stride(0))
+        ctx.save_for_backward(agg2, c2, ih, hs, upd, w_ih_c, w_hs, w_out_c, DEVICE_SEED if p_out > 0.0 else None)
+        ctx.cfg = (float(p_out), int(seed_out), tuple(res.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        agg, c, ih, hs, upd, w_ih, w_hs, w_out, seed_dev = ctx.saved_tensors
+        p_out, seed_out, res_shape = ctx.cfg
+        n, d = agg.shape
+        dev = agg.device
+        st = _stream(agg)
+        dy2 = _rows2(dy)
+        if p_out > 0.0:
+            dz = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), None, 0, 0, p_out, seed_out, _p(seed_dev), n, d, _p(dz),
+                      d, st)
+        else:
+            dz = dy2
+        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", n, d, d),
+                            _lib.query("hivt_linear_wgrad_workspace_bytes", n, 2 * d, d)), dev)
+
+        def wgrad(g, g_ld, x, x_ld, rows_out):
+            dw = torch.empty(rows_out, d, dtype=torch.float32, device=dev)
+            db = torch.empty(rows_out, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_wgrad", _p(g), g_ld, _p(x), x_ld, n, rows_out, d, _p(dw), _p(db), _p(ws), ws.numel(), st)
+            return dw, db
+
+        def data_grad(g, g_ld, w, rows_out, add=None):
+            dx = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_bwd_data", _p(g), g_ld, _p(w), w.stride(0), n, rows_out, d, None, 0, 1.0, _p(add),
+                      d if add is not None else 0, _p(dx), d, st)
+            return dx
+
+        dw_out, db_out = wgrad(dz, dz.stride(0), upd, d, d)
+        d_upd = data_grad(dz, dz.stride(0), w_out, d)
+        d_agg_direct = torch.empty(n, d, dtype=torch.float32, device=dev)
+        d_ih = torch.empty(n, d, dtype=torch.float32, device=dev)
+        d_hs = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_gated_update_bwd", _p(d_upd), _p(agg), agg.stride(0), _p(ih), d, _p(hs), 2 * d, _p(hs, 4 * d),
+                  2 * d, n, d, _p(d_agg_direct), _p(d_ih), _p(d_hs), 2 * d, _p(d_hs, 4 * d), 2 * d, st)
+        dw_ih, db_ih = wgrad(d_ih, d, agg, agg.stride(0), d)
+        d_agg = data_grad(d_ih, d, w_ih, d, add=d_agg_direct)  # both routes into the aggregated messages
+        dw_hs, db_hs = wgrad(d_hs, 2 * d, c, c.stride(0), 2 * d)
+        d_c = data_grad(d_hs, 2 * d, w_hs, 2 * d)
+        return (d_agg, d_c, dy.reshape(res_shape), dw_ih, db_ih, dw_hs[:d], db_hs[:d], dw_hs[d:], db_hs[d:], dw_out,
+                db_out, None, None)
+
+
+def gated_update_tail(agg: torch.Tensor, center: torch.Tensor, residual: torch.Tensor, lin_ih, lin_hh, lin_self,
+                      out_proj, p_out: float, training: bool) -> torch.Tensor:
+    """Gate, update, output projection, dropout and residual of an edge-attention block as one autograd
+    node (``agg``, ``center``, ``residual`` [N, D] GPU tensors)."""
+    p = float(p_out) if training else 0.0
+    return _GatedUpdateTail.apply(agg, center, residual, lin_ih.weight, lin_ih.bias, lin_hh.weight, lin_hh.bias,
+                                  lin_self.weight, lin_self.bias, out_proj.weight, out_proj.bias, p,
+                                  _fresh_seed() if p > 0.0 else 0)

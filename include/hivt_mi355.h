@@ -237,10 +237,13 @@ int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_l
  * mask (may be NULL, [M,K] with row stride mask_ld): x was itself the output of a ReLU [+ dropout] epilogue,
  * and the gradient is carried through it in the same pass: dx = mask > 0 ? dx * mask_scale : 0, with
  * mask = that output and mask_scale = 1 / (1 - its dropout probability) -- the step from the second to the
- * first Linear of a feed-forward block (models/local_encoder.py:117-122,279). */
+ * first Linear of a feed-forward block (models/local_encoder.py:117-122,279).
+ * add (may be NULL, [M,K] with row stride add_ld; not together with mask): dx += add, for an input that
+ * also reaches the loss by another route (the aggregated messages feed both the gate's lin_ih and the
+ * update itself, models/local_encoder.py:186-188). */
 int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
-                         int32_t K, const float* mask, int64_t mask_ld, float mask_scale, float* dx, int64_t dx_ld,
-                         hivt_stream_t stream);
+                         int32_t K, const float* mask, int64_t mask_ld, float mask_scale, const float* add,
+                         int64_t add_ld, float* dx, int64_t dx_ld, hivt_stream_t stream);
 
 /* Workspace for hivt_linear_wgrad. */
 size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);

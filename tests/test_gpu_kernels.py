@@ -764,3 +764,43 @@ def test_pre_norm_feed_forward_block(M, D, p):
     assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     for g, r, name in zip(got, [x.grad] + [q.grad for q in params], ["x", "gamma", "beta", "w1", "b1", "w2", "b2"]):
         assert float((g - r).abs().max()) <= 3e-5 * float(r.abs().max()), name
+
+
+@pytest.mark.parametrize("N,D", [(900, 128), (2623, 64)])
+def test_gated_update_tail_block(N, D):
+    """Gate + update + out_proj + residual as one autograd node against the framework ops
+    (local_encoder.py:183-188,197-199), all eleven gradients."""
+    torch.manual_seed(N)
+    dev = torch.device("cuda", 0)
+    lin_ih, lin_hh, lin_self, out_proj = (torch.nn.Linear(D, D).to(dev) for _ in range(4))
+    agg = torch.randn(N, D, device=dev, requires_grad=True)
+    c = torch.randn(N, D, device=dev, requires_grad=True)
+    res = torch.randn(N, D, device=dev, requires_grad=True)
+    gy = torch.randn(N, D, device=dev)
+    leaves = [agg, c, res] + [p for m in (lin_ih, lin_hh, lin_self, out_proj) for p in (m.weight, m.bias)]
+    y = ops.gated_update_tail(agg, c, res, lin_ih, lin_hh, lin_self, out_proj, 0.1, False)
+    y.backward(gy)
+    got = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    gate = torch.sigmoid(lin_ih(agg) + lin_hh(c))
+    ref = res + out_proj(agg + gate * (lin_self(c) - agg))
+    ref.backward(gy)
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    for g, t in zip(got, leaves):
+        assert float((g - t.grad).abs().max()) <= 3e-5 * float(t.grad.abs().max())
+    # with dropout: kept fraction and forward / backward mask agreement through the residual-free part
+    torch.manual_seed(1)
+    y = ops.gated_update_tail(agg, c, res, lin_ih, lin_hh, lin_self, out_proj, 0.25, True)
+    kept = ((y.detach() - res.detach()).abs() > 0).float()
+    assert abs(float(kept.mean()) - 0.75) < 0.01
+    for t in leaves:
+        t.grad = None
+    y.backward(gy)
+    assert torch.equal(res.grad, gy)
+    ref_d = res + kept / 0.75 * out_proj(agg + gate.detach() * 0 + torch.sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg))
+    for t in leaves:
+        t.grad = None
+    ref_d.backward(gy)
+    y2_err = float((y.detach() - ref_d.detach()).abs().max())
+    assert y2_err <= 3e-5 * float(ref_d.abs().max())

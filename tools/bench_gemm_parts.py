@@ -33,7 +33,7 @@ for (M, K, N) in [(136_000, 128, 128), (136_000, 128, 256), (136_000, 256, 128),
     db = torch.empty(N, device=dev)
     ws = torch.empty(_lib.query("hivt_linear_wgrad_workspace_bytes", M, N, K), dtype=torch.uint8, device=dev)
     s = ops._stream(x)
-    t_bd = timeit(lambda: _lib.call("hivt_linear_bwd_data", dy.data_ptr(), N, w.data_ptr(), K, M, N, K, None, 0, 1.0,
+    t_bd = timeit(lambda: _lib.call("hivt_linear_bwd_data", dy.data_ptr(), N, w.data_ptr(), K, M, N, K, None, 0, 1.0, None, 0,
                                     dx.data_ptr(), K, s))
     t_bd_s = timeit(lambda: torch.mm(dy, w, out=dx))
     t_wg = timeit(lambda: _lib.call("hivt_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, M, N, K, dw.data_ptr(),
