@@ -804,3 +804,94 @@ def test_gated_update_tail_block(N, D):
     ref_d.backward(gy)
     y2_err = float((y.detach() - ref_d.detach()).abs().max())
     assert y2_err <= 3e-5 * float(ref_d.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# dense kernels at the training step's largest sizes (grids of more than a thousand tiles)
+# ---------------------------------------------------------------------------------------------
+def _close_scale(a, b, rtol, msg):
+    err = float((a.double() - b.double()).abs().max())
+    scale = max(float(b.double().abs().max()), 1e-30)
+    assert err <= rtol * scale, f"{msg}: {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,K,N,relu,use_add,use_res", [
+    (70_001, 128, 128, False, False, False), (66_000, 64, 128, True, False, False), (40_003, 128, 256, True, True, False),
+    (33_000, 256, 384, False, False, True), (70_000, 512, 128, False, False, True), (136_000, 128, 128, False, True, False)])
+def test_linear_kernels_large_grids(M, K, N, relu, use_add, use_res):
+    """Forward (bias, added rows, ReLU, residual) and the data / weight gradients at the sizes of the
+    full training step, against float64 framework ops on the same device."""
+    torch.manual_seed(M % 1000 + K + N)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV, requires_grad=True)
+    add = torch.randn(M, N, device=DEV, requires_grad=True) if use_add else None
+    res = torch.randn(M, N, device=DEV, requires_grad=True) if use_res else None
+    gy = torch.randn(M, N, device=DEV)
+    y = ops.fused_linear(x, w, b, add=add, relu=relu, residual=res)
+    y.backward(gy)
+    leaves = [t for t in (x, w, b, add, res) if t is not None]
+    got = [t.grad.clone() for t in leaves]
+    d = [t.detach().double().requires_grad_(True) for t in leaves]
+    it = iter(d)
+    xd, wd, bd = next(it), next(it), next(it)
+    ref = torch.nn.functional.linear(xd, wd, bd)
+    if use_add:
+        ref = ref + next(it)
+    if relu:  # the on/off decision of units within rounding of zero is taken from the kernel's output
+        ref = ref * (y.detach() > 0)
+    if use_res:
+        ref = ref + next(it)
+    ref.backward(gy.double())
+    _close_scale(y, ref, 1e-5, "y")
+    for name, g, t in zip(["dx", "dw", "db", "d4", "d5"], got, d):
+        _close_scale(g, t.grad, 2e-5, name)
+
+
+def test_linear_dropout_and_blocks_large_grids():
+    """Dropout + residual epilogue (kept fraction, forward / backward mask agreement) and the two block
+    nodes whose data-gradient products use the gating mask and the added second route, at the row counts
+    of the full training step."""
+    torch.manual_seed(11)
+    M, D, p = 70_000, 128, 0.2
+    x = torch.randn(M, D, device=DEV, requires_grad=True)
+    lin = torch.nn.Linear(D, D).to(DEV)
+    res = torch.randn(M, D, device=DEV)
+    gy = torch.randn(M, D, device=DEV)
+    y = ops.fused_linear(x, lin.weight, lin.bias, dropout_p=p, training=True, residual=res)
+    kept = (y.detach() - res) != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.005
+    y.backward(gy)
+    pre = torch.nn.functional.linear(x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double())
+    _close_scale(y, res.double() + pre * kept / (1 - p), 1e-5, "y with dropout")
+    dx_ref = (gy.double() * kept / (1 - p)) @ lin.weight.detach().double()
+    _close_scale(x.grad, dx_ref, 2e-5, "dx with dropout")
+
+    # feed-forward block: the gating mask rides in the second Linear's data-gradient product
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    lin1, lin2 = torch.nn.Linear(D, 4 * D).to(DEV), torch.nn.Linear(4 * D, D).to(DEV)
+    x2 = torch.randn(M, D, device=DEV, requires_grad=True)
+    out = ops.pre_norm_feed_forward(x2, norm, lin1, 0.0, lin2, 0.0, False)
+    out.backward(gy)
+    got = [x2.grad.clone(), lin1.weight.grad.clone(), lin2.weight.grad.clone(), norm.weight.grad.clone()]
+    x2.grad = lin1.weight.grad = lin2.weight.grad = norm.weight.grad = None
+    ref = x2 + lin2(torch.relu(lin1(norm(x2))))
+    ref.backward(gy)
+    _close_scale(out, ref, 2e-5, "feed-forward block")
+    for name, g, r in zip(["dx", "dw1", "dw2", "dgamma"], got, [x2.grad, lin1.weight.grad, lin2.weight.grad, norm.weight.grad]):
+        _close_scale(g, r, 1e-4, "feed-forward block " + name)
+
+    # gated update tail: the aggregated messages receive two gradient routes in one product
+    lin_ih, lin_hh, lin_self, out_proj = (torch.nn.Linear(D, D).to(DEV) for _ in range(4))
+    agg = torch.randn(M, D, device=DEV, requires_grad=True)
+    c = torch.randn(M, D, device=DEV, requires_grad=True)
+    r = torch.randn(M, D, device=DEV, requires_grad=True)
+    out = ops.gated_update_tail(agg, c, r, lin_ih, lin_hh, lin_self, out_proj, 0.0, False)
+    out.backward(gy.clone())  # the residual's gradient is the incoming tensor itself: keep gy out of reach
+    got = [agg.grad.clone(), c.grad.clone()]
+    agg.grad = c.grad = r.grad = None
+    ref = r + out_proj(agg + torch.sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg))
+    ref.backward(gy)
+    _close_scale(out, ref, 2e-5, "update tail")
+    _close_scale(got[0], agg.grad, 1e-4, "update tail d_agg")
+    _close_scale(got[1], c.grad, 1e-4, "update tail d_center")
