@@ -19,6 +19,7 @@ namespace {
 
 constexpr float kNegSentinel = -1.0e30f;  // "no edge seen yet"; exp(kNegSentinel - x) == 0
 constexpr int kUnrollLong = 4;   // edges in flight per lane slot
+constexpr int kUnrollWide = 8;   // rows split over four waves: a 64-edge row is one batch of loads per wave
 constexpr int kUnrollShort = 2;  // short-row mode: rows average under two edges, a wider batch is mostly masked work
 
 struct SegAttnArgs {
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
   constexpr int RPW = SPLIT ? EPI : 1;
-  constexpr int kUnroll = SPLIT ? kUnrollShort : kUnrollLong;
+  constexpr int kUnroll = SPLIT ? kUnrollShort : (WPN > 1 ? kUnrollWide : kUnrollLong);
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   const int h = c / LPH;
   const int win = wave % WPN;
   const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
-  if (!SPLIT && n >= a.N) return;  // block-uniform when WPN == 4
+  if (!SPLIT && WPN == 1 && n >= a.N) return;  // with WPN > 1 every wave stays for the barrier (row_ok gates the work)
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
 
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? EPI : 1;
-  constexpr int kUnroll = SPLIT ? kUnrollShort : kUnrollLong;
+  constexpr int kUnroll = SPLIT ? kUnrollShort : (WPN > 1 ? kUnrollWide : kUnrollLong);
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
 
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   const int h = c / LPH;
   const int win = wave % WPN;
   const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
-  if (!SPLIT && n >= a.N) return;
+  if (!SPLIT && WPN == 1 && n >= a.N) return;
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
 
