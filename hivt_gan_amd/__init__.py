@@ -18,6 +18,7 @@ from .local_encoder import (AAEncoder, ALEncoder, DistanceDropEdge, EdgePlan, Lo
                             TemporalEncoderLayer, build_edge_plan, subgraph)
 from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss, R1Regularization,
                      SoftTargetCrossEntropyLoss, fused_supervised_losses)
+from .metrics import ADE, FDE, MR, EndpointDiversity, Jerk, SpeedViolation, ValidationMetrics
 from .trainer import GanTrainer
 
 __all__ = [
@@ -26,5 +27,6 @@ __all__ = [
     "ShortScaleCritic", "MidScaleCritic", "LongScaleCritic", "LaplaceNLLLoss", "SoftTargetCrossEntropyLoss",
     "R1Regularization", "AdversarialDiscriminatorLoss", "AdversarialGeneratorLoss", "fused_supervised_losses", "HiVT",
     "TemporalData", "collate", "make_scene", "make_batch", "DistanceDropEdge", "EdgePlan", "build_edge_plan",
-    "subgraph", "init_weights", "GanTrainer", "BatchSpec", "pad_batch",
+    "subgraph", "init_weights", "GanTrainer", "BatchSpec", "pad_batch", "ADE", "FDE", "MR", "Jerk", "SpeedViolation",
+    "EndpointDiversity", "ValidationMetrics",
 ]

@@ -25,6 +25,7 @@ from .critics import LongScaleCritic, MidScaleCritic, ShortScaleCritic
 from .decoder import MLPDecoder
 from .global_interactor import GlobalInteractor
 from .local_encoder import LocalEncoder
+from .metrics import ValidationMetrics
 from .optim import FusedAdamW
 from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss,
                      SoftTargetCrossEntropyLoss, fused_supervised_losses, join_critic_streams)
@@ -135,6 +136,37 @@ class HiVT(nn.Module):
         fake = y_hat[best_mode, torch.arange(n, device=y_hat.device), :, :2]
         keep = (~data["padding_mask"][:, self.historical_steps:]).any(dim=1)
         return data["y"], fake, keep
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def validation_step(self, data, metrics: Optional[ValidationMetrics] = None) -> Dict[str, torch.Tensor]:
+        """Forward pass plus the reference's validation quantities (``models/hivt.py:347-393``): the
+        regression loss of the best mode over all valid agents, and for each scene's target agent
+        (``agent_index``) the trajectory of the mode with the smallest final displacement, from which
+        minADE / minFDE / minMR and the realism metrics are accumulated into ``metrics``.  Nothing is
+        read back: a batch without any valid future step enters the running loss with weight 0 (the
+        reference returns early there).  Returns the batch's own values as device tensors."""
+        y_hat, pi = self(data)
+        reg_loss, _cls, _best = self._supervised_losses(data, y_hat, pi)
+        has_future = (~data["padding_mask"][:, self.historical_steps:]).any()
+        usable = has_future & torch.isfinite(reg_loss)
+        agent = data["agent_index"]
+        y_hat_agent = y_hat[:, agent, :, :2]                                     # [F, B, H, 2]
+        y_agent = data["y"][agent]                                               # [B, H, 2]
+        fde = torch.norm(y_hat_agent[:, :, -1] - y_agent[:, -1], p=2, dim=-1)    # [F, B]
+        best_mode_agent = fde.argmin(dim=0)
+        best = y_hat_agent[best_mode_agent, torch.arange(agent.shape[0], device=y_hat.device)]
+        if metrics is not None:
+            metrics.val_reg_loss._add(torch.where(usable, reg_loss, torch.zeros_like(reg_loss)), usable)
+            metrics.minADE.update(best, y_agent)
+            metrics.minFDE.update(best, y_agent)
+            metrics.minMR.update(best, y_agent)
+            metrics.jerk.update(best)
+            metrics.speed_violation.update(best)
+            metrics.endpoint_diversity.update(y_hat_agent)
+        ade = torch.norm(best - y_agent, p=2, dim=-1).mean(dim=-1)
+        return {"val_reg_loss": reg_loss, "val_minADE": ade.mean(), "val_minFDE": fde.min(dim=0).values.mean(),
+                "best_mode_agent": best_mode_agent}
 
     # ------------------------------------------------------------------------------------------
     def training_step(self, data, opt_g: torch.optim.Optimizer, opt_d: Optional[torch.optim.Optimizer] = None,

@@ -506,3 +506,44 @@ def test_temporal_last_position_equals_full_layer_row():
         assert (a is None) == (b is None), k
         if a is not None:
             assert_close(a, b, 3e-5, msg=k)
+
+
+def test_validation_step_metrics_vs_oracle_forward():
+    """validation_step on the GPU: regression loss, the target agents' best-by-endpoint trajectories and
+    minADE / minFDE / minMR against the same quantities computed from the CPU path's predictions
+    (models/hivt.py:347-378)."""
+    torch.manual_seed(2022)
+    model = hv.HiVT(**CFG64, lr=5e-4, weight_decay=1e-4, T_max=64).to(DEV)
+    model.eval()
+    b = hv.make_batch(6)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        y_ref, pi_ref, y_rot = O.hivt_forward(sd, batch_tensors(b), dict(CFG64), training=False)
+        reg_ref, _cls, _best = O.supervised_losses(y_ref, pi_ref, y_rot, b["padding_mask"], 20)
+    agent = b["agent_index"]
+    ya = y_rot[agent]
+    pa = y_ref[:, agent, :, :2]
+    fde = (pa[:, :, -1] - ya[:, -1]).norm(dim=-1)
+    best = pa[fde.argmin(dim=0), torch.arange(agent.shape[0])]
+    want_ade = float((best - ya).norm(dim=-1).mean(dim=-1).mean())
+    want_fde = float(fde.min(dim=0).values.mean())
+    want_mr = float((fde.min(dim=0).values > 2.0).float().mean())
+    vm = hv.ValidationMetrics()
+    out = model.validation_step(b.to(DEV), vm)
+    got = vm.compute()
+    assert torch.equal(out["best_mode_agent"].cpu(), fde.argmin(dim=0))
+    assert abs(float(got["val_minADE"]) - want_ade) <= 2e-5 * max(1.0, want_ade)
+    assert abs(float(got["val_minFDE"]) - want_fde) <= 2e-5 * max(1.0, want_fde)
+    assert abs(float(got["val_minMR"]) - want_mr) <= 1e-6
+    assert abs(float(got["val_reg_loss"]) - float(reg_ref)) <= 2e-5 * max(1.0, abs(float(reg_ref)))
+    assert abs(float(out["val_minADE"]) - want_ade) <= 2e-5 * max(1.0, want_ade)
+    assert float(got["val_jerk"]) >= 0.0 and 0.0 <= float(got["val_speed_violation"]) <= 1.0
+    assert float(got["val_endpoint_diversity"]) > 0.0
+    # a second batch accumulates; a batch without any future step leaves the running loss alone
+    b2 = hv.make_batch(4, first_index=50)
+    model.validation_step(b2.to(DEV), vm)
+    b3 = hv.make_batch(3, first_index=80)
+    b3["padding_mask"][:, 20:] = True
+    before = float(vm.val_reg_loss.count)
+    model.validation_step(b3.to(DEV), vm)
+    assert float(vm.val_reg_loss.count) == before == 2.0 and float(vm.minADE.count) == 13.0
