@@ -64,8 +64,11 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None, bad: Optional[torch.Tensor] = None) -> None:
         self.pack(bad)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(dist.get_world_size(group))
+        if dist.get_backend(group) == "nccl":  # RCCL averages inside the collective
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
         self.unpack()
 
 
