@@ -468,6 +468,14 @@ def linear_fused_supported(n_out: int, layer_norm: bool) -> bool:
     return (not layer_norm) or n_out <= 128
 
 
+def _pass_through_grad(dy: torch.Tensor, shape, to_leaf: bool) -> torch.Tensor:
+    """Gradient of an operand that was only added to the output: the incoming gradient itself.  A leaf
+    keeps what it is handed as its ``.grad`` and later accumulates into it in place, so it gets a copy
+    (a view sharing ``dy``'s memory would let that accumulation reach every other holder of ``dy``)."""
+    g = dy.reshape(shape)
+    return g.clone() if to_leaf else g
+
+
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
@@ -513,6 +521,7 @@ class _FusedLinear(torch.autograd.Function):
         ctx.cfg = (bool(relu), ln, tuple(lead), bias is not None, add is not None,
                    tuple(add.shape) if add is not None else None, float(dropout_p), int(seed),
                    tuple(residual.shape) if residual is not None else None)
+        ctx.res_leaf = residual is not None and residual.is_leaf
         return y.view(*lead, n)
 
     @staticmethod
@@ -563,7 +572,8 @@ class _FusedLinear(torch.autograd.Function):
                 ws = _workspace(_lib.query("hivt_rowsum_by_code_workspace_bytes", m, n, codes), dev)
                 _lib.call("hivt_rowsum_by_code", _p(dz), dz.stride(0), _p(add_index), m, n, codes, _p(dadd), _p(ws),
                           ws.numel(), s)
-        dres = dy.reshape(res_shape) if (res_shape is not None and ctx.needs_input_grad[11]) else None
+        dres = _pass_through_grad(dy, res_shape, ctx.res_leaf) \
+            if (res_shape is not None and ctx.needs_input_grad[11]) else None
         return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres
 
 
@@ -1223,6 +1233,7 @@ class _GatedUpdateTail(torch.autograd.Function):
         linear(upd, d, w_out_c, b_out_c, d, y, p_out, seed_out, r2, r2.stride(0))
         ctx.save_for_backward(agg2, c2, ih, hs, upd, w_ih_c, w_hs, w_out_c, DEVICE_SEED if p_out > 0.0 else None)
         ctx.cfg = (float(p_out), int(seed_out), tuple(res.shape))
+        ctx.res_leaf = res.is_leaf
         return y
 
     @staticmethod
@@ -1266,7 +1277,7 @@ class _GatedUpdateTail(torch.autograd.Function):
         d_agg = data_grad(d_ih, d, w_ih, d, add=d_agg_direct)  # both routes into the aggregated messages
         dw_hs, db_hs = wgrad(d_hs, 2 * d, c, c.stride(0), 2 * d)
         d_c = data_grad(d_hs, 2 * d, w_hs, 2 * d)
-        return (d_agg, d_c, dy.reshape(res_shape), dw_ih, db_ih, dw_hs[:d], db_hs[:d], dw_hs[d:], db_hs[d:], dw_out,
+        return (d_agg, d_c, _pass_through_grad(dy, res_shape, ctx.res_leaf), dw_ih, db_ih, dw_hs[:d], db_hs[:d], dw_hs[d:], db_hs[d:], dw_out,
                 db_out, None, None)
 
 

@@ -887,11 +887,14 @@ def test_linear_dropout_and_blocks_large_grids():
     c = torch.randn(M, D, device=DEV, requires_grad=True)
     r = torch.randn(M, D, device=DEV, requires_grad=True)
     out = ops.gated_update_tail(agg, c, r, lin_ih, lin_hh, lin_self, out_proj, 0.0, False)
-    out.backward(gy.clone())  # the residual's gradient is the incoming tensor itself: keep gy out of reach
+    out.backward(gy)
     got = [agg.grad.clone(), c.grad.clone()]
-    agg.grad = c.grad = r.grad = None
+    assert r.grad.data_ptr() != gy.data_ptr()  # a leaf residual gets its own copy of the incoming gradient
+    agg.grad = c.grad = None                   # r.grad stays: the second backward accumulates into it in place
+    gy_before = gy.clone()
     ref = r + out_proj(agg + torch.sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg))
     ref.backward(gy)
     _close_scale(out, ref, 2e-5, "update tail")
     _close_scale(got[0], agg.grad, 1e-4, "update tail d_agg")
     _close_scale(got[1], c.grad, 1e-4, "update tail d_center")
+    assert torch.equal(gy, gy_before) and torch.equal(r.grad, 2 * gy)
