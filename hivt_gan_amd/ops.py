@@ -522,6 +522,7 @@ class _FusedLinear(torch.autograd.Function):
                    tuple(add.shape) if add is not None else None, float(dropout_p), int(seed),
                    tuple(residual.shape) if residual is not None else None)
         ctx.res_leaf = residual is not None and residual.is_leaf
+        ctx.add_leaf = add is not None and add.is_leaf
         return y.view(*lead, n)
 
     @staticmethod
@@ -565,7 +566,7 @@ class _FusedLinear(torch.autograd.Function):
         dadd = None
         if has_add and ctx.needs_input_grad[3]:
             if add_index is None:
-                dadd = dz.view(add_shape)
+                dadd = _pass_through_grad(dz, add_shape, ctx.add_leaf)
             else:  # gradient of the table: per-code sums of the rows of dz
                 codes = add_shape[0]
                 dadd = torch.empty(codes, n, dtype=torch.float32, device=dev)
