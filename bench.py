@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--matmul", choices=("fp32", "bf16"), default="fp32",
+                    help="operand precision of the dense products (bf16: fp32 accumulation, results within 2e-2)")
     ap.add_argument("--no-tune", action="store_true", help="keep the default launch schedule (no timing of alternatives)")
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
@@ -138,6 +140,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    ops.set_matmul_precision(args.matmul)
     torch.manual_seed(2022)
     model = hv.HiVT(**model_config(args.embed_dim)).to(dev)
     model.train()
@@ -207,12 +210,15 @@ def main():
             "metric": "train scenes/sec (G+D+R1 step)", "value": world * args.scenes * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.matmul == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"HiVT-{args.embed_dim} full G+D+R1 train step, {args.scenes} synthetic "
                                    f"nuScenes-shaped scenes per GPU per step, dropout 0.1, AdamW x2",
                        "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
                        "guards": "host" if args.host_guards else "device",
-                       "discarded_steps": trainer.overflowed_steps(), "tuned": tuned},
+                       "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,
+                       "precision": "fp32 throughout" if args.matmul == "fp32" else
+                       "dense products on bf16 operands with fp32 accumulation; attention, norms, losses, "
+                       "optimizer state fp32"},
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
         }

@@ -77,9 +77,13 @@ SIGNATURES = {
     "hivt_hinge_r1_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P]),
     "hivt_weighted_mean_fwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_weighted_mean_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_set_matmul_bf16": (c_int, [c_int]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
+
+# entry points whose int return value is an answer rather than an error code
+INT_VALUED = ("hivt_version", "hivt_set_matmul_bf16")
 
 _lib = None
 
@@ -133,7 +137,7 @@ def _function(name: str):
             fn = getattr(fast, name)
         else:
             cfn = getattr(load(), name)
-            if cfn.restype is c_int and name != "hivt_version":
+            if cfn.restype is c_int and name not in INT_VALUED:
                 def fn(*args, _cfn=cfn, _name=name):
                     rc = _cfn(*args)
                     if rc != 0:
@@ -167,3 +171,8 @@ def query(name: str, *args) -> int:
         conv = [(ctypes.c_int32 * len(a))(*a) if isinstance(a, tuple) else a for a in args]  # tuples: int32 arrays
         size = _sizes[key] = int(_function(name)(*conv))
     return size
+
+
+def value(name: str, *args) -> int:
+    """Invoke an entry point that returns an integer answer (no caching, no error mapping)."""
+    return int(_function(name)(*args))

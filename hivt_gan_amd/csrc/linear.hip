@@ -15,10 +15,15 @@
 
 #include <math.h>
 
+#include <atomic>
+
 namespace hivt {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
@@ -50,9 +55,14 @@ struct Operand {
   int32_t vec_ok; // 16-byte vector loads are legal (alignment + multiples of 4)
 };
 
-template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false>
+// BF16: the LDS image holds bfloat16 [row][k] (k contiguous, row pitch kBK + 4 halves = 72 bytes: the
+// 8-byte operand reads of 32 consecutive rows then fall on 32 distinct bank pairs); values are rounded
+// to nearest-even on their way from the fp32 registers to LDS, sums that leave the stage stay fp32.
+template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, bool BF16 = false>
 struct Stage {
   static constexpr int PITCH = TRANS ? ROWS + 1 : ROWS + 4;
+  static constexpr int PITCH_H = kBK + 4;  // halves per row of the bf16 image
+  static constexpr int FLOATS = BF16 ? ROWS * PITCH_H / 2 : kBK * PITCH;  // LDS floats of one staged step
   static constexpr int NVEC = ROWS * kBK / 4 / kThreads;  // float4 per thread per step
   float4 v[NVEC];
   unsigned ok;  // 4 validity bits per float4; applied when the values are written to LDS
@@ -116,7 +126,24 @@ struct Stage {
       colsum.z += val.z;
       colsum.w += val.w;
     }
-    if (TRANS) {
+    if (BF16) {
+      const f32x4 f = {val.x, val.y, val.z, val.w};
+      const bf16x4 h = __builtin_convertvector(f, bf16x4);
+      unsigned short* image = reinterpret_cast<unsigned short*>(lds);
+      if (TRANS) {  // four consecutive k of one row: one 8-byte store
+        const int row = idx / (kBK / 4);
+        const int red = (idx % (kBK / 4)) * 4;
+        *reinterpret_cast<bf16x4*>(image + row * PITCH_H + red) = h;
+      } else {      // one k of four consecutive rows
+        const int red = idx / (ROWS / 4);
+        const int row = (idx % (ROWS / 4)) * 4;
+        const s16x4 bits = __builtin_bit_cast(s16x4, h);
+        image[(row + 0) * PITCH_H + red] = (unsigned short)bits[0];
+        image[(row + 1) * PITCH_H + red] = (unsigned short)bits[1];
+        image[(row + 2) * PITCH_H + red] = (unsigned short)bits[2];
+        image[(row + 3) * PITCH_H + red] = (unsigned short)bits[3];
+      }
+    } else if (TRANS) {
       const int row = idx / (kBK / 4);
       const int red = (idx % (kBK / 4)) * 4;
       lds[(red + 0) * PITCH + row] = val.x;
@@ -159,12 +186,12 @@ struct Tail {
 // DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
 // step s is multiplied (used for small grids, where no other workgroup shares the compute unit to
 // hide the load latency behind; it costs registers, hence occupancy, on large grids).
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false, bool BF16 = false>
 struct Core {
-  using SA = Stage<BM, TA, VEC, ACC_A>;
-  using SB = Stage<BN, TB, VEC>;
-  static constexpr int A_FLOATS = kBK * SA::PITCH;
-  static constexpr int B_FLOATS = kBK * SB::PITCH;
+  using SA = Stage<BM, TA, VEC, ACC_A, BF16>;
+  using SB = Stage<BN, TB, VEC, false, BF16>;
+  static constexpr int A_FLOATS = SA::FLOATS;
+  static constexpr int B_FLOATS = SB::FLOATS;
   static constexpr int C_PITCH = BN + 4;
   static constexpr int STAGE_FLOATS = 2 * (A_FLOATS + B_FLOATS);
   static constexpr int C_FLOATS = BM * C_PITCH;
@@ -196,6 +223,28 @@ struct Core {
     // between(kp) runs after the MFMAs of k-pair kp (0..15): work placed there is issued while the
     // matrix unit is busy.
     auto multiply = [&](int cur, auto&& between) {
+      if constexpr (BF16) {
+        // v_mfma_f32_32x32x8_bf16: lane (row lo, half hi) supplies k = 4*hi .. 4*hi + 3 of its row;
+        // four MFMAs per accumulator cover the 32 k of a step, all twelve operand reads go first
+        const unsigned short* image = reinterpret_cast<const unsigned short*>(lds + cur);
+        const unsigned short* pa = image + (wr * 32 + lo) * SA::PITCH_H + 4 * hi;
+        const unsigned short* pb = image + 2 * A_FLOATS + (wc * 64 + lo) * SB::PITCH_H + 4 * hi;
+        s16x4 av[kBK / 8], b0[kBK / 8], b1[kBK / 8];
+#pragma unroll
+        for (int g = 0; g < kBK / 8; ++g) {
+          av[g] = *reinterpret_cast<const s16x4*>(pa + 8 * g);
+          b0[g] = *reinterpret_cast<const s16x4*>(pb + 8 * g);
+          b1[g] = *reinterpret_cast<const s16x4*>(pb + 32 * SB::PITCH_H + 8 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < kBK / 8; ++g) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av[g], b0[g], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av[g], b1[g], acc1, 0, 0, 0);
+          between(4 * g + 1);
+          between(4 * g + 3);
+        }
+        return;
+      }
       const int ao = cur + wr * 32 + lo;
       const int bo = cur + A_FLOATS + wc * 64 + lo;
       constexpr int HALF = kBK / 4;  // k-pairs per half
@@ -413,9 +462,9 @@ struct FwdArgs {
   int32_t M, N;
 };
 
-template <int BM, int BN, int EPI, bool VEC, bool DEEP = false>
+template <int BM, int BN, int EPI, bool VEC, bool DEEP = false, bool BF16 = false>
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
-  using C = Core<BM, BN, true, true, VEC, false, DEEP>;
+  using C = Core<BM, BN, true, true, VEC, false, DEEP, BF16>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   Operand xa = a.x, wa = a.w;
@@ -526,9 +575,9 @@ struct BwdDataArgs {
   int64_t add_ld;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false>
+template <int BM, int BN, bool VEC, bool DEEP = false, bool BF16 = false>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
-  using C = Core<BM, BN, true, false, VEC, false, DEEP>;
+  using C = Core<BM, BN, true, false, VEC, false, DEEP, BF16>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
@@ -557,9 +606,9 @@ struct WgradArgs {
   int32_t N, K, M, chunk_rows;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false>
+template <int BM, int BN, bool VEC, bool DEEP = false, bool BF16 = false>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
-  using C = Core<BM, BN, false, false, VEC, true, DEEP>;
+  using C = Core<BM, BN, false, false, VEC, true, DEEP, BF16>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   __shared__ float bsum[kThreads / (BM / 4)][BM];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
@@ -893,6 +942,10 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
   }
 }
 
+// Operand precision of the three products: 0 = fp32 (exact), 1 = bfloat16 operands with fp32 accumulation.
+// Process-wide, set through hivt_set_matmul_bf16(); read once per call on the host.
+std::atomic<int> g_matmul_bf16{0};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans) {
@@ -927,6 +980,10 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
 }  // namespace hivt
 
 using namespace hivt;
+
+extern "C" int hivt_set_matmul_bf16(int enable) {
+  return g_matmul_bf16.exchange(enable != 0 ? 1 : 0, std::memory_order_relaxed);
+}
 
 #ifdef HIVT_PROBE
 extern "C" int hivt_probe_set(long long* buffer) {
@@ -967,9 +1024,14 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
+  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
   // grids that leave compute units with a single workgroup get the deep-prefetch variant
 #define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
-  if (vec && grid.x * grid.y <= kSmallGrid)                                                                  \
+  if (vec && bf16 && grid.x * grid.y <= kSmallGrid)                                                          \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, true>), grid, dim3(kThreads), 0, s, a);  \
+  else if (vec && bf16)                                                                                      \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, false, true>), grid, dim3(kThreads), 0, s, a); \
+  else if (vec && grid.x * grid.y <= kSmallGrid)                                                             \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true>), grid, dim3(kThreads), 0, s, a);        \
   else if (vec)                                                                                              \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true>), grid, dim3(kThreads), 0, s, a);              \
@@ -1015,9 +1077,14 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   a.add = add; a.add_ld = add_ld;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
+  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
   if (K <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), 1);
-    if (vec && grid.x <= kSmallGrid)
+    if (vec && bf16 && grid.x <= kSmallGrid)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec && bf16)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, false, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec && grid.x <= kSmallGrid)
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true>), grid, dim3(kThreads), 0, s, a);
     else if (vec)
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true>), grid, dim3(kThreads), 0, s, a);
@@ -1025,7 +1092,11 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, false>), grid, dim3(kThreads), 0, s, a);
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 127) / 128));
-    if (vec && grid.x * grid.y <= kSmallGrid)
+    if (vec && bf16 && grid.x * grid.y <= kSmallGrid)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec && bf16)
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, false, true>), grid, dim3(kThreads), 0, s, a);
+    else if (vec && grid.x * grid.y <= kSmallGrid)
       hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
     else if (vec)
       hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);
@@ -1070,7 +1141,12 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   a.bias_partial = dbias ? a.partial + (size_t)N * K : nullptr;
   a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
-  if (a.dy.vec_ok && a.x.vec_ok && grid.x * grid.y * grid.z <= kSmallGrid)
+  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
+  if (a.dy.vec_ok && a.x.vec_ok && bf16 && grid.x * grid.y * grid.z <= kSmallGrid)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, true>), grid, dim3(kThreads), 0, s, a);
+  else if (a.dy.vec_ok && a.x.vec_ok && bf16)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, false, true>), grid, dim3(kThreads), 0, s, a);
+  else if (a.dy.vec_ok && a.x.vec_ok && grid.x * grid.y * grid.z <= kSmallGrid)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true>), grid, dim3(kThreads), 0, s, a);

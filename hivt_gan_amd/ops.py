@@ -476,6 +476,15 @@ def _pass_through_grad(dy: torch.Tensor, shape, to_leaf: bool) -> torch.Tensor:
     return g.clone() if to_leaf else g
 
 
+def set_matmul_precision(precision: str) -> str:
+    """``"fp32"`` (default: exact fp32 products) or ``"bf16"`` (operands of every dense product rounded to
+    bfloat16, fp32 accumulation; results within about 1e-2 of the fp32 ones).  Process-wide switch of the
+    library; returns the previous setting."""
+    if precision not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    return "bf16" if _lib.value("hivt_set_matmul_bf16", 1 if precision == "bf16" else 0) else "fp32"
+
+
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod

@@ -439,6 +439,13 @@ int hivt_weighted_mean_fwd(const float* s, const float* w, const float* count, i
 int hivt_weighted_mean_bwd(const float* g_out, const float* w, const float* count, int64_t B, float scale, float* g_s,
                            hivt_stream_t stream);
 
+/* Operand precision of hivt_linear_fwd / hivt_linear_bwd_data / hivt_linear_wgrad (and of everything built
+ * on them): 0 (default) = fp32 operands on the fp32 matrix instructions, exact; non-zero = operands rounded
+ * to bfloat16 (nearest even) on their way into LDS and multiplied by v_mfma_f32_32x32x8_bf16 with fp32
+ * accumulation -- inputs, outputs, epilogues, bias sums and reductions stay fp32.  Process-wide; returns
+ * the previous setting.  No counterpart in the reference, which trains in fp32 throughout. */
+int hivt_set_matmul_bf16(int enable);
+
 #ifdef __cplusplus
 }
 #endif
