@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--matmul", choices=("fp32", "bf16"), default="fp32",
                     help="operand precision of the dense products (bf16: fp32 accumulation, results within 2e-2)")
+    ap.add_argument("--no-variant", action="store_true",
+                    help="skip the extra timing of the step with the other --matmul precision")
     ap.add_argument("--no-tune", action="store_true", help="keep the default launch schedule (no timing of alternatives)")
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
@@ -166,26 +168,40 @@ def main():
     tuned = trainer.tune(run_step) if not args.no_tune else {}
     for i in range(args.warmup):
         run_step(i)
+    def timed(first: int, steps: int) -> float:
+        """Seconds for ``steps`` steps between two barrier + synchronize brackets, max over ranks."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            timed.logs = run_step(first + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     records = []
     ops.SEG_ATTN_TIMING = records
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        logs = run_step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.warmup, args.steps)
     ops.SEG_ATTN_TIMING = None
+    logs = timed.logs
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # the same step with the other operand precision of the dense products, timed the same way after the
+    # headline measurement (reported beside it, never as ``value``)
+    other = None
+    if not args.no_variant:
+        name = "bf16" if args.matmul == "fp32" else "fp32"
+        ops.set_matmul_precision(name)
+        for i in range(3):
+            run_step(i)
+        other = (name, timed(args.warmup + args.steps, args.steps))
+        ops.set_matmul_precision(args.matmul)
 
     if rank == 0:
         groups = {}
@@ -222,6 +238,12 @@ def main():
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
         }
+        if other is not None:
+            result["matmul_variant"] = {"matmul": other[0], "ms_per_step": other[1] / args.steps * 1e3,
+                                        "value": world * args.scenes * args.steps / other[1], "unit": "scenes/sec",
+                                        "note": "same step and schedule, dense products on "
+                                                + ("bf16 operands (fp32 accumulation, results within 2e-2)"
+                                                   if other[0] == "bf16" else "fp32 operands")}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.embed_dim, args.cpu_scenes, args.cpu_steps)
         print(json.dumps(result))

@@ -5,7 +5,7 @@ set -e
 SETTING=$1
 ROUNDS=${2:-2}
 for i in $(seq $ROUNDS); do
-  a=$(timeout -k 10 200 python bench.py --no-cpu-baseline --no-tune 2>/dev/null | python -c "import json,sys; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])")
-  b=$(env $SETTING timeout -k 10 200 python bench.py --no-cpu-baseline --no-tune 2>/dev/null | python -c "import json,sys; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])")
+  a=$(timeout -k 10 200 python bench.py --no-cpu-baseline --no-tune --no-variant 2>/dev/null | python -c "import json,sys; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])")
+  b=$(env $SETTING timeout -k 10 200 python bench.py --no-cpu-baseline --no-tune --no-variant 2>/dev/null | python -c "import json,sys; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])")
   echo "default $a ms/step | $SETTING $b ms/step"
 done

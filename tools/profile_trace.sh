@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/trace
 SCR=/tmp/trace_run
 mkdir -p "$OUT" "$SCR"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$SCR" -o t -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-tune > "$OUT/bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$SCR" -o t -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --no-tune --no-variant > "$OUT/bench.log" 2>&1
 python3 - "$SCR" > "$OUT/linear_by_grid.txt" <<'PY'
 import csv, glob, sys, re
 from collections import defaultdict
