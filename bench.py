@@ -134,8 +134,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL is the data path; HIVT_DIST_BACKEND=gloo exists to rehearse the multi-rank control flow on a
+    # box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("HIVT_DIST_BACKEND", "nccl")
+    local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -181,7 +188,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

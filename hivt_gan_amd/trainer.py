@@ -1,5 +1,5 @@
 """Driver of the G + D + R1 step on one rank: optimizers, LR schedule, data-parallel gradient
-averaging, and replay of the whole step as HIP graphs.
+averaging, and the choice of the launch schedule by measurement.
 
 Data parallelism.  The reference wraps the whole LightningModule in DDP with
 ``find_unused_parameters=True`` (``train.py:69-78``), so every 25 MB bucket of all 2.9 M parameters
@@ -10,7 +10,7 @@ anyway (``models/hivt.py:312``).  The payloads are latency-bound on xGMI, so eac
 ONE concatenation into a contiguous fp32 buffer, reduced with a single RCCL all-reduce (backend name
 "nccl" on ROCm), and handed back to the parameters as views of that buffer.
 
-Host synchronisation.  One step is about 2300 kernel launches of a few microseconds each, so the
+Host synchronisation.  One step is about 1100 kernel launches of a few microseconds each, so the
 host, not the GPU, limits an eagerly launched step, and every read-back stalls the launch stream on
 top of that.  With ``edge_capacity`` (see ``GanTrainer.calibrate``) the trainer runs the step with
 no read-back at all: the filtered edge lists keep a fixed capacity and every kernel takes the live
@@ -27,6 +27,17 @@ import torch.distributed as dist
 
 from .data import BatchSpec, TemporalData
 from .hivt import HiVT
+
+
+def _is_rccl(group=None) -> bool:
+    return dist.get_backend(group) == "nccl"
+
+
+def _all_reduce_sum_via_host(t: torch.Tensor, group=None) -> None:
+    """Sum of a device tensor over the ranks of a CPU backend (gloo): staged through host memory."""
+    host = t.detach().cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(host)
 
 
 class FlatGradBucket:
@@ -64,10 +75,13 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None, bad: Optional[torch.Tensor] = None) -> None:
         self.pack(bad)
-        if dist.get_backend(group) == "nccl":  # RCCL averages inside the collective
+        if _is_rccl(group):  # RCCL averages inside the collective
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if self.flat.is_cuda:
+                _all_reduce_sum_via_host(self.flat, group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
         self.unpack()
 
@@ -122,7 +136,12 @@ class GanTrainer:
     def broadcast_state(self) -> None:
         """Rank 0's parameters and buffers everywhere (what DDP does at construction)."""
         for t in list(self.model.parameters()) + list(self.model.buffers()):
-            dist.broadcast(t.data, src=0)
+            if t.is_cuda and not _is_rccl():  # CPU backend: through host memory
+                host = t.data.cpu()
+                dist.broadcast(host, src=0)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=0)
 
     def _sync(self, group: str, bad: Optional[torch.Tensor] = None) -> None:
         self.buckets[group].all_reduce_mean(bad=bad)
@@ -162,7 +181,10 @@ class GanTrainer:
                 spent[mode] += time.perf_counter() - t0
         vote = torch.tensor([1.0 if spent[True] <= spent[False] else 0.0], device="cuda")
         if self.distributed:
-            dist.all_reduce(vote)
+            if _is_rccl():
+                dist.all_reduce(vote)
+            else:
+                _all_reduce_sum_via_host(vote)
             vote /= dist.get_world_size()
         losses.CONCURRENT_CRITICS = bool(vote.item() >= 0.5)
         return {"critic_streams": losses.CONCURRENT_CRITICS}

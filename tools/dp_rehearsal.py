@@ -1,0 +1,105 @@
+"""Two data-parallel ranks sharing cuda:0 over gloo: the multi-rank control flow of ``GanTrainer`` with
+the real GPU model (RCCL needs one device per rank, so this rehearses everything but the transport).
+
+Each rank logs its stages to gpurun_out/dp_rank<r>.log and dumps its Python stack if it stalls.
+Checks: ranks hold identical parameters after every step, the losses are finite, and the first
+step's reduced generator gradient equals the mean of the two ranks' local gradients.
+"""
+import faulthandler
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def worker(rank, world, port, steps):
+    log = open(os.path.join(OUT, f"dp_rank{rank}.log"), "w", buffering=1)
+    faulthandler.dump_traceback_later(60, exit=True, file=log)
+
+    def say(*a):
+        print(*a, file=log)
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import hivt_gan_amd as hv
+    from bench import model_config
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    say("group up")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(2022)
+    cfg = model_config(64)
+    cfg["dropout"] = 0.0
+    model = hv.HiVT(**cfg).to(dev)
+    model.train()
+    pool = [hv.make_batch(16, first_index=(rank * 4 + i) * 16).to(dev) for i in range(4)]
+    ys = [b["y"] for b in pool]
+    capacity = hv.GanTrainer.calibrate(model, pool).edge_capacity
+    say("calibrated")
+    trainer = hv.GanTrainer(model, edge_capacity=capacity)
+    say("trainer built, distributed =", trainer.distributed)
+
+    def run_step(i):
+        b = pool[i % len(pool)]
+        b["y"] = ys[i % len(pool)]
+        b["edge_plan"] = None
+        return trainer.step(b)
+
+    local = {}
+    plain_sync = trainer._sync
+
+    def recording_sync(group, bad=None):
+        if group not in local:
+            local[group] = trainer.buckets[group].pack().clone()
+        plain_sync(group, bad)
+        local.setdefault(group + "_reduced", trainer.buckets[group].flat.clone())
+    trainer._sync = recording_sync
+
+    for i in range(steps):
+        logs = run_step(i)
+        torch.cuda.synchronize()
+        say("step", i, {k: round(float(v), 5) for k, v in logs.items() if v.numel() == 1})
+        state = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+        both = [torch.empty_like(state) for _ in range(world)]
+        dist.all_gather(both, state)
+        assert torch.equal(both[0], both[1]), f"ranks diverged after step {i}"
+        assert all(bool(torch.isfinite(v).all()) for v in logs.values())
+        if i == 0:
+            for group in ("critic", "generator"):
+                mine = local[group].cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                mean = (parts[0] + parts[1]) / 2
+                err = float((local[group + "_reduced"].cpu() - mean).abs().max())
+                scale = float(mean.abs().max())
+                say(group, "reduced vs mean of locals: err", err, "scale", scale)
+                assert scale > 0 and err <= 1e-6 * scale
+    trainer._sync = plain_sync
+    tuned = trainer.tune(run_step)
+    say("tuned", tuned)
+    for i in range(3):
+        run_step(steps + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    say("OK")
+    faulthandler.cancel_dump_traceback_later()
+    dist.destroy_process_group()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(2, port, 4), nprocs=2, join=True)
+    print("dp rehearsal OK")
+
+
+if __name__ == "__main__":
+    main()
