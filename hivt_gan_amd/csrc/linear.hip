@@ -652,18 +652,20 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   }
 }
 
-// out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: four row slices are summed
+// out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: SLICES row slices are summed
 // independently (ascending r inside a slice) and then combined in slice order, so the result does
-// not depend on scheduling.  One block covers 64 columns; each thread sums one slice of one column.
+// not depend on scheduling.  One block covers COLS columns; each thread sums one slice of one column.
 // Columns at or beyond `split` go to out1[c - split] (two result vectors from one partial buffer).
+template <int COLS, int SLICES>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
-                                                          int C, float* __restrict__ out, int split = 0x7fffffff,
-                                                          float* __restrict__ out1 = nullptr) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sl = threadIdx.x >> 6;
-  const int per = (R + 3) / 4;
-  const int r0 = sl * per, r1 = min(R, r0 + per);
+                                                          int C, float* __restrict__ out, int split,
+                                                          float* __restrict__ out1) {
+  static_assert(COLS * SLICES == 256, "one thread per (column, slice)");
+  __shared__ float part[SLICES][COLS];
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + col;
+  const int per = (R + SLICES - 1) / SLICES;
+  const int r0 = min(R, sl * per), r1 = min(R, r0 + per);
   float s = 0.0f;
   if (c < C) {
     int r = r0;
@@ -676,15 +678,28 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
     for (; r < r1; ++r) s += partial[(int64_t)r * pitch + c];
   }
-  part[sl][threadIdx.x & 63] = s;
+  part[sl][col] = s;
   __syncthreads();
   if (sl == 0 && c < C) {
-    const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    float t = part[0][col];
+#pragma unroll
+    for (int i = 1; i < SLICES; ++i) t += part[i][col];
     if (c < split)
       out[c] = t;
     else
       out1[c - split] = t;
   }
+}
+
+// Many partial rows: sixteen slices of sixteen-column blocks shorten each thread's serial chain.
+static void launch_reduce_rows(hipStream_t s, const float* partial, int R, int64_t pitch, int C, float* out,
+                               int split = 0x7fffffff, float* out1 = nullptr) {
+  if (R >= 64)
+    hipLaunchKernelGGL((reduce_rows_kernel<16, 16>), dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, partial, R, pitch,
+                       C, out, split, out1);
+  else
+    hipLaunchKernelGGL((reduce_rows_kernel<64, 4>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, R, pitch,
+                       C, out, split, out1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -973,8 +988,7 @@ int pick_chunks(int64_t M, int tiles) {
 }  // namespace
 
 void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, stream, partial, rows,
-                     (int64_t)cols, cols, out, 0x7fffffff, (float*)nullptr);
+  launch_reduce_rows(stream, partial, rows, (int64_t)cols, cols, out);
 }
 
 }  // namespace hivt
@@ -1155,16 +1169,23 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   HIVT_CHECK_LAUNCH(what);
   // one reduction over the chunks for the weight sums and (columns beyond N*K) the bias sums
   const int cnt = N * K, cols = (int)a.pitch;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, s, a.partial, real_chunks,
-                     a.pitch, cols, dw, cnt, dbias);
+  launch_reduce_rows(s, a.partial, real_chunks, a.pitch, cols, dw, cnt, dbias);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
 
-extern "C" size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N) {
+// Workgroups of the LayerNorm-backward kernel = rows of its partial-sum buffer: enough waves to keep
+// HBM busy on long inputs, few enough that the reduction over the partial rows stays short.
+static int64_t ln_bwd_blocks(int64_t M) {
+  const int64_t cap = M >= 40000 ? 1024 : 512;
   int64_t blocks = (M + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+extern "C" size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N) {
+  const int64_t blocks = ln_bwd_blocks(M);
   return align_up((size_t)blocks * 2 * (size_t)N * sizeof(float), 256);
 }
 
@@ -1185,8 +1206,7 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
   HIVT_REQUIRE(dy && z && stats && gamma && beta && dz, HIVT_ERR_ARG, "%s: null pointer", what);
   HIVT_REQUIRE(workspace && workspace_bytes >= hivt_ln_bwd_workspace_bytes(M, N), HIVT_ERR_WORKSPACE,
                "%s: workspace too small", what);
-  int64_t blocks = (M + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  const int64_t blocks = ln_bwd_blocks(M);
   float* partial = reinterpret_cast<float*>(workspace);
   auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
   const int vec = (al8(dy) && al8(z) && al8(dz) && dy_ld % 2 == 0 && z_ld % 2 == 0 && dz_ld % 2 == 0) ? 1 : 0;
@@ -1198,8 +1218,7 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
                        beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
   HIVT_CHECK_LAUNCH(what);
   // partial is [blocks][2][N]: one reduction over the 2N columns, first half -> dgamma, second -> dbeta
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((2 * N + 63) / 64)), dim3(256), 0, s, partial, (int)blocks,
-                     (int64_t)2 * N, 2 * N, dgamma, N, dbeta);
+  launch_reduce_rows(s, partial, (int)blocks, (int64_t)2 * N, 2 * N, dgamma, N, dbeta);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
