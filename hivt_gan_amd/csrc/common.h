@@ -59,6 +59,17 @@ inline void zero_words(void* p, int64_t words, hipStream_t stream) {
 // out[c] = sum over r < rows of partial[r * cols + c], summed in a fixed order (deterministic).
 void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream);
 
+// Dense products whose result passes through the derivative of Dropout(LeakyReLU(.)) recovered from the
+// activation's saved output `gate` ([M, columns of the result]):
+//   out *= gate > 0 ? pos_scale : gate < 0 ? neg_scale : 0
+// y[M,N] = x[M,K] w[N,K]^T gated, and dx[M,K] = dy[M,N] w[N,K] gated.
+int linear_fwd_gated(const float* x, int64_t x_ld, const float* w, int64_t w_ld, int64_t M, int32_t N, int32_t K,
+                     const float* gate, int64_t gate_ld, float pos_scale, float neg_scale, float* y, int64_t y_ld,
+                     hivt_stream_t stream);
+int linear_bwd_data_gated(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N, int32_t K,
+                          const float* gate, int64_t gate_ld, float pos_scale, float neg_scale, float* dx,
+                          int64_t dx_ld, hivt_stream_t stream);
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -301,14 +301,13 @@ extern "C" int hivt_critic_fwd(const float* x, int64_t x_ld, int64_t B, int32_t 
   HIVT_CHECK_LAUNCH(what);
   for (int l = layers; l >= 1; --l) {
     float* g_prev = l > 1 ? saved + s.g_off[l - 1] : saved + s.g0_off;
-    HIVT_TRY(hivt_linear_bwd_data(saved + s.g_off[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0,
-                                  1.0f, nullptr, 0, g_prev, s.w[l - 1], stream));
-    if (l > 1) {
-      hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,
-                         (const float*)g_prev, (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l - 1],
-                         keep_scale, neg_slope, B, s.w[l - 1], g_prev);
-      HIVT_CHECK_LAUNCH(what);
-    }
+    if (l > 1)  // through the activation of layer l - 1, inside the product's epilogue
+      HIVT_TRY(linear_bwd_data_gated(saved + s.g_off[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1],
+                                     saved + s.h_off[l - 1], s.w[l - 1], keep_scale, keep_scale * neg_slope, g_prev,
+                                     s.w[l - 1], stream));
+    else
+      HIVT_TRY(hivt_linear_bwd_data(saved + s.g_off[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0,
+                                    1.0f, nullptr, 0, g_prev, s.w[l - 1], stream));
   }
   hipLaunchKernelGGL(row_sumsq_kernel, dim3((unsigned)((B + 3) / 4 > 2048 ? 2048 : (B + 3) / 4)), dim3(256), 0, st,
                      (const float*)(saved + s.g0_off), B, s.w[0], grad_norm2);
@@ -374,13 +373,14 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
                                    k.wgrad_ws, k.wgrad_bytes, stream));
       if (l > 1 || dx != nullptr) {
         float* dh = (l == 1) ? dx : other;
-        HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f, nullptr, 0, dh,
-                                      s.w[l - 1], stream));
         if (l > 1) {
-          hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l - 1])), dim3(256), 0, st,
-                             (const float*)dh, (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l - 1],
-                             keep_scale, neg_slope, B, s.w[l - 1], dh);
-          HIVT_CHECK_LAUNCH(what);
+          HIVT_TRY(linear_bwd_data_gated(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], saved + s.h_off[l - 1],
+                                         s.w[l - 1], keep_scale, keep_scale * neg_slope, dh, s.w[l - 1], stream));
+        } else {
+          HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f,
+                                        nullptr, 0, dh, s.w[l - 1], stream));
+        }
+        if (l > 1) {
           float* t = dz;
           dz = dh;
           other = t;
@@ -413,13 +413,8 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
         HIVT_CHECK_LAUNCH(what);
       }
       // e_l = (e_{l-1} W_l^T) * c_l
-      HIVT_TRY(hivt_linear_fwd(e, s.w[l - 1], w[l - 1], s.w[l - 1], nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                               0.0f, 0, 1.0f, 0.0f, 0, nullptr, nullptr, 0, B, s.w[l], s.w[l - 1], t, s.w[l], nullptr,
-                               0, nullptr, stream));
-      hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[l])), dim3(256), 0, st, (const float*)t,
-                         (const float*)nullptr, (const float*)nullptr, saved + s.h_off[l], keep_scale, neg_slope, B,
-                         s.w[l], t);
-      HIVT_CHECK_LAUNCH(what);
+      HIVT_TRY(linear_fwd_gated(e, s.w[l - 1], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], saved + s.h_off[l], s.w[l],
+                                keep_scale, keep_scale * neg_slope, t, s.w[l], stream));
       float* sw = e;
       e = t;
       t = sw;

@@ -178,9 +178,11 @@ struct Tail {
   const float* residual = nullptr;
   int64_t res_ld = 0;
   // residual_is_mask: the tensor in `residual` is not added; it gates the value instead:
-  // out = residual > 0 ? value * mask_scale : 0 (gradient through a ReLU [+ dropout] whose output it is)
+  // out = value * (residual > 0 ? mask_scale : residual < 0 ? mask_neg_scale : 0): the gradient through a
+  // ReLU or LeakyReLU [+ dropout] whose output `residual` is (a dropped element is exactly 0)
   bool residual_is_mask = false;
   float mask_scale = 1.0f;
+  float mask_neg_scale = 0.0f;
 };
 
 // DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
@@ -431,8 +433,8 @@ struct Core {
         }
         if (t.residual != nullptr) {
           if (t.residual_is_mask) {
-            v0 = res0[r] > 0.0f ? v0 * t.mask_scale : 0.0f;
-            v1 = res1[r] > 0.0f ? v1 * t.mask_scale : 0.0f;
+            v0 = res0[r] > 0.0f ? v0 * t.mask_scale : (res0[r] < 0.0f ? v0 * t.mask_neg_scale : 0.0f);
+            v1 = res1[r] > 0.0f ? v1 * t.mask_scale : (res1[r] < 0.0f ? v1 * t.mask_neg_scale : 0.0f);
           } else {
             v0 += res0[r];
             v1 += res1[r];
@@ -568,9 +570,9 @@ struct BwdDataArgs {
   float* dx;
   int64_t dx_ld;
   int32_t M, K;
-  const float* mask;  // optional [M,K]: dx = mask > 0 ? dx * mask_scale : 0
+  const float* mask;  // optional [M,K]: dx *= mask > 0 ? mask_scale : mask < 0 ? mask_neg_scale : 0
   int64_t mask_ld;
-  float mask_scale;
+  float mask_scale, mask_neg_scale;
   const float* add;   // optional [M,K], exclusive with mask: dx += add
   int64_t add_ld;
 };
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
     t.res_ld = a.mask_ld;
     t.residual_is_mask = true;
     t.mask_scale = a.mask_scale;
+    t.mask_neg_scale = a.mask_neg_scale;
   } else {
     t.residual = a.add;
     t.res_ld = a.add_ld;
@@ -1005,13 +1008,15 @@ extern "C" int hivt_probe_set(long long* buffer) {
 }
 #endif
 
-extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
-                               const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
-                               const float* gamma, const float* beta, float eps,
-                               int epilogue, float neg_slope, float dropout_p, uint64_t seed,
-                               const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N,
-                               int32_t K, float* y,
-                               int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream) {
+// gate_pos / gate_neg: with gate_pos != 0 the tensor in `residual` gates the result instead of being added
+static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
+                           const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
+                           const float* gamma, const float* beta, float eps,
+                           int epilogue, float neg_slope, float dropout_p, uint64_t seed,
+                           const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N,
+                           int32_t K, float* y,
+                           int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream,
+                           float gate_pos, float gate_neg) {
   const char* what = "hivt_linear_fwd";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LN_RELU, HIVT_ERR_ARG, "%s: unknown epilogue %d", what,
@@ -1034,6 +1039,11 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
                "%s: a LeakyReLU slope goes with the plain epilogue only", what);
   a.t.neg_slope = neg_slope;
   a.t.drop_p = dropout_p; a.t.seed = seed; a.t.seed_ptr = seed_ptr; a.t.residual = residual; a.t.res_ld = res_ld;
+  if (gate_pos != 0.0f && residual != nullptr) {
+    a.t.residual_is_mask = true;
+    a.t.mask_scale = gate_pos;
+    a.t.mask_neg_scale = gate_neg;
+  }
   a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
@@ -1074,10 +1084,22 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
   return HIVT_OK;
 }
 
-extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
-                                    int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
-                                    const float* add, int64_t add_ld, float* dx, int64_t dx_ld,
-                                    hivt_stream_t stream) {
+extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, const float* bias,
+                               const float* add, int64_t add_ld, const int32_t* add_index, int32_t add_rows,
+                               const float* gamma, const float* beta, float eps,
+                               int epilogue, float neg_slope, float dropout_p, uint64_t seed,
+                               const uint64_t* seed_ptr, const float* residual, int64_t res_ld, int64_t M, int32_t N,
+                               int32_t K, float* y,
+                               int64_t y_ld, float* z, int64_t z_ld, float* stats, hivt_stream_t stream) {
+  return linear_fwd_impl(x, x_ld, w, w_ld, bias, add, add_ld, add_index, add_rows, gamma, beta, eps, epilogue, neg_slope,
+                         dropout_p, seed, seed_ptr, residual, res_ld, M, N, K, y, y_ld, z, z_ld, stats, stream, 0.0f,
+                         0.0f);
+}
+
+static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
+                                int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
+                                float mask_neg_scale, const float* add, int64_t add_ld, float* dx, int64_t dx_ld,
+                                hivt_stream_t stream) {
   const char* what = "hivt_linear_bwd_data";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   if (M == 0) return HIVT_OK;
@@ -1087,7 +1109,7 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   a.w = make_operand(w, w_ld, K, N, false);  // W[n][k]: reduction index n is the row of the memory image
   a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K;
   HIVT_REQUIRE(mask == nullptr || add == nullptr, HIVT_ERR_UNSUPPORTED, "%s: mask and add are exclusive", what);
-  a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale;
+  a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale; a.mask_neg_scale = mask_neg_scale;
   a.add = add; a.add_ld = add_ld;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
@@ -1120,6 +1142,33 @@ extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float*
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
+
+extern "C" int hivt_linear_bwd_data(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
+                                    int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
+                                    const float* add, int64_t add_ld, float* dx, int64_t dx_ld,
+                                    hivt_stream_t stream) {
+  return linear_bwd_data_impl(dy, dy_ld, w, w_ld, M, N, K, mask, mask_ld, mask_scale, 0.0f, add, add_ld, dx, dx_ld,
+                              stream);
+}
+
+namespace hivt {
+
+int linear_fwd_gated(const float* x, int64_t x_ld, const float* w, int64_t w_ld, int64_t M, int32_t N, int32_t K,
+                     const float* gate, int64_t gate_ld, float pos_scale, float neg_scale, float* y, int64_t y_ld,
+                     hivt_stream_t stream) {
+  return linear_fwd_impl(x, x_ld, w, w_ld, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.0f, EPI_NONE, 1.0f,
+                         0.0f, 0, nullptr, gate, gate_ld, M, N, K, y, y_ld, nullptr, 0, nullptr, stream, pos_scale,
+                         neg_scale);
+}
+
+int linear_bwd_data_gated(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N, int32_t K,
+                          const float* gate, int64_t gate_ld, float pos_scale, float neg_scale, float* dx,
+                          int64_t dx_ld, hivt_stream_t stream) {
+  return linear_bwd_data_impl(dy, dy_ld, w, w_ld, M, N, K, gate, gate_ld, pos_scale, neg_scale, nullptr, 0, dx, dx_ld,
+                              stream);
+}
+
+}  // namespace hivt
 
 extern "C" size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
