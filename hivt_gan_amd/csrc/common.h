@@ -57,7 +57,13 @@ inline void zero_words(void* p, int64_t words, hipStream_t stream) {
 }
 
 // out[c] = sum over r < rows of partial[r * cols + c], summed in a fixed order (deterministic).
-void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream);
+// out[c] (+)= sum over rows of partial[row][c], rows summed in a fixed order
+void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream,
+                     bool accumulate = false);
+
+// dw[N,K] += dy[M,N]^T x[M,K] (hivt_linear_wgrad without the bias sums, added to what dw holds)
+int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                            int32_t K, float* dw, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
 // Dense products whose result passes through the derivative of Dropout(LeakyReLU(.)) recovered from the
 // activation's saved output `gate` ([M, columns of the result]):

@@ -69,13 +69,6 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict_
   }
 }
 
-// dst[i] += src[i]
-__global__ __launch_bounds__(256) void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                       int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dst[i] += src[i];
-}
-
 inline unsigned blocks_for(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 2048) b = 2048;
@@ -404,14 +397,12 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
     HIVT_CHECK_LAUNCH(what);
     for (int l = 1; l <= layers; ++l) {
       // dW_l (+)= G_l^T e_{l-1}
-      float* target = accumulate ? k.wtmp : dw[l - 1];
-      HIVT_TRY(hivt_linear_wgrad(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], target, nullptr,
-                                 k.wgrad_ws, k.wgrad_bytes, stream));
-      if (accumulate) {
-        const int64_t n = (int64_t)s.w[l] * s.w[l - 1];
-        hipLaunchKernelGGL(add_into_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dw[l - 1], (const float*)k.wtmp, n);
-        HIVT_CHECK_LAUNCH(what);
-      }
+      if (accumulate)
+        HIVT_TRY(linear_wgrad_accumulate(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], dw[l - 1],
+                                         k.wgrad_ws, k.wgrad_bytes, stream));
+      else
+        HIVT_TRY(hivt_linear_wgrad(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], dw[l - 1], nullptr,
+                                   k.wgrad_ws, k.wgrad_bytes, stream));
       // e_l = (e_{l-1} W_l^T) * c_l
       HIVT_TRY(linear_fwd_gated(e, s.w[l - 1], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], saved + s.h_off[l], s.w[l],
                                 keep_scale, keep_scale * neg_slope, t, s.w[l], stream));
@@ -420,14 +411,7 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
       t = sw;
     }
     // dw_o (+)= column sums of e_L (rows summed in a fixed order)
-    if (accumulate) {
-      reduce_partials(e, (int)B, s.w[layers], k.wtmp, st);
-      HIVT_CHECK_LAUNCH(what);
-      hipLaunchKernelGGL(add_into_kernel, dim3(blocks_for(s.w[layers])), dim3(256), 0, st, dw[layers],
-                         (const float*)k.wtmp, (int64_t)s.w[layers]);
-    } else {
-      reduce_partials(e, (int)B, s.w[layers], dw[layers], st);
-    }
+    reduce_partials(e, (int)B, s.w[layers], dw[layers], st, accumulate);
     HIVT_CHECK_LAUNCH(what);
   }
   return HIVT_OK;

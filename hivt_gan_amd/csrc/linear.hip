@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
 template <int COLS, int SLICES>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
                                                           int C, float* __restrict__ out, int split,
-                                                          float* __restrict__ out1) {
+                                                          float* __restrict__ out1, int accumulate) {
   static_assert(COLS * SLICES == 256, "one thread per (column, slice)");
   __shared__ float part[SLICES][COLS];
   const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
@@ -687,22 +687,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     float t = part[0][col];
 #pragma unroll
     for (int i = 1; i < SLICES; ++i) t += part[i][col];
-    if (c < split)
-      out[c] = t;
-    else
-      out1[c - split] = t;
+    float* dst = c < split ? out + c : out1 + (c - split);
+    *dst = accumulate ? *dst + t : t;  // accumulate: the sum is added to what the output holds
   }
 }
 
 // Many partial rows: sixteen slices of sixteen-column blocks shorten each thread's serial chain.
 static void launch_reduce_rows(hipStream_t s, const float* partial, int R, int64_t pitch, int C, float* out,
-                               int split = 0x7fffffff, float* out1 = nullptr) {
+                               int split = 0x7fffffff, float* out1 = nullptr, int accumulate = 0) {
   if (R >= 64)
     hipLaunchKernelGGL((reduce_rows_kernel<16, 16>), dim3((unsigned)((C + 15) / 16)), dim3(256), 0, s, partial, R, pitch,
-                       C, out, split, out1);
+                       C, out, split, out1, accumulate);
   else
     hipLaunchKernelGGL((reduce_rows_kernel<64, 4>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, R, pitch,
-                       C, out, split, out1);
+                       C, out, split, out1, accumulate);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -990,8 +988,8 @@ int pick_chunks(int64_t M, int tiles) {
 
 }  // namespace
 
-void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream) {
-  launch_reduce_rows(stream, partial, rows, (int64_t)cols, cols, out);
+void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream, bool accumulate) {
+  launch_reduce_rows(stream, partial, rows, (int64_t)cols, cols, out, 0x7fffffff, nullptr, accumulate ? 1 : 0);
 }
 
 }  // namespace hivt
@@ -1176,14 +1174,15 @@ extern "C" size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_
   return align_up((size_t)chunks * ((size_t)N * K + (size_t)N) * sizeof(float), 256);
 }
 
-extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
-                                 int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                                 hivt_stream_t stream) {
+static int linear_wgrad_impl(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                             int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                             hivt_stream_t stream, bool accumulate) {
   const char* what = "hivt_linear_wgrad";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(dw != nullptr, HIVT_ERR_ARG, "%s: dw is null", what);
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) {
+    if (accumulate) return HIVT_OK;
     zero_words(dw, (int64_t)N * K, s);
     if (dbias) zero_words(dbias, N, s);
     HIVT_CHECK_LAUNCH(what);
@@ -1218,10 +1217,23 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   HIVT_CHECK_LAUNCH(what);
   // one reduction over the chunks for the weight sums and (columns beyond N*K) the bias sums
   const int cnt = N * K, cols = (int)a.pitch;
-  launch_reduce_rows(s, a.partial, real_chunks, a.pitch, cols, dw, cnt, dbias);
+  launch_reduce_rows(s, a.partial, real_chunks, a.pitch, cols, dw, cnt, dbias, accumulate ? 1 : 0);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
+
+extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                                 int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                 hivt_stream_t stream) {
+  return linear_wgrad_impl(dy, dy_ld, x, x_ld, M, N, K, dw, dbias, workspace, workspace_bytes, stream, false);
+}
+
+namespace hivt {
+int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                            int32_t K, float* dw, void* workspace, size_t workspace_bytes, hivt_stream_t stream) {
+  return linear_wgrad_impl(dy, dy_ld, x, x_ld, M, N, K, dw, nullptr, workspace, workspace_bytes, stream, true);
+}
+}  // namespace hivt
 
 // Workgroups of the LayerNorm-backward kernel = rows of its partial-sum buffer: enough waves to keep
 // HBM busy on long inputs, few enough that the reduction over the partial rows stays short.
