@@ -21,6 +21,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import ops
 from .critics import LongScaleCritic, MidScaleCritic, ShortScaleCritic
 from .decoder import MLPDecoder
 from .global_interactor import GlobalInteractor
@@ -183,8 +184,12 @@ class HiVT(nn.Module):
         evaluated on the host (two read-backs per step).  With ``sync_free`` they stay on the device:
         without data parallelism the optimizers skip their update through ``found_inf`` (fused AdamW),
         with it the rank contributes zero gradients -- the same outcomes without any synchronisation."""
-        if self.sync_free:
-            return self._training_step_sync_free(data, opt_g, opt_d, sync_grads)
+        with ops.seed_scope():  # one draw of the host generator for all dropout seeds of the step
+            if self.sync_free:
+                return self._training_step_sync_free(data, opt_g, opt_d, sync_grads)
+            return self._training_step_guarded(data, opt_g, opt_d, sync_grads)
+
+    def _training_step_guarded(self, data, opt_g, opt_d, sync_grads) -> Dict[str, torch.Tensor]:
 
         def skip(reason: str) -> Dict[str, torch.Tensor]:
             # zero-gradient participation keeps data-parallel ranks in lock-step

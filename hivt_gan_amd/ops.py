@@ -5,6 +5,7 @@ functions.  PyTorch supplies device memory, the current stream and autograd book
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -265,15 +266,38 @@ def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args
 # under torch.manual_seed).  When DEVICE_SEED is set (a uint64-as-int64 device scalar owned by the
 # caller) the kernels add its current value to a per-call constant instead, so a caller that
 # re-issues identical launches still draws new masks as long as it advances the scalar.
+#
+# Inside ``seed_scope()`` (one training step) all seeds derive from ONE draw of the CPU generator and a
+# call counter, which saves the forty-odd generator calls of a step; seeding torch before the scope
+# still reproduces every mask of the scope.
 DEVICE_SEED: Optional[torch.Tensor] = None
 _seed_calls = 0
+_scope_base: Optional[int] = None
+_scope_calls = 0
+_SEED_MASK = (1 << 62) - 1
+_GOLDEN = 0x9E3779B97F4A7C15
+
+
+@contextlib.contextmanager
+def seed_scope():
+    global _scope_base, _scope_calls
+    outer = (_scope_base, _scope_calls)
+    _scope_base = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    _scope_calls = 0
+    try:
+        yield
+    finally:
+        _scope_base, _scope_calls = outer
 
 
 def _fresh_seed() -> int:
-    global _seed_calls
+    global _seed_calls, _scope_calls
     if DEVICE_SEED is not None:
         _seed_calls += 1
-        return (_seed_calls * 0x9E3779B97F4A7C15) & ((1 << 62) - 1)
+        return (_seed_calls * _GOLDEN) & _SEED_MASK
+    if _scope_base is not None:
+        _scope_calls += 1
+        return (_scope_base + _scope_calls * _GOLDEN) & _SEED_MASK
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
