@@ -224,3 +224,27 @@ def test_kernels_refuse_cpu_tensors():
         ops.csr_build(torch.zeros(4, dtype=torch.int32), 3)
     with pytest.raises(RuntimeError, match="GPU only"):
         ops.gated_update(torch.zeros(2, 8), torch.zeros(2, 8), torch.zeros(2, 16))
+
+
+def test_seed_scope_is_reproducible_and_nests():
+    import torch
+    from hivt_gan_amd import ops
+
+    def draw():
+        torch.manual_seed(77)
+        with ops.seed_scope():
+            first = [ops._fresh_seed() for _ in range(5)]
+            with ops.seed_scope():
+                inner = ops._fresh_seed()
+            first.append(ops._fresh_seed())  # the outer counter continues after the nested scope
+        return first, inner
+
+    a, inner_a = draw()
+    b, inner_b = draw()
+    assert a == b and inner_a == inner_b
+    assert len(set(a + [inner_a])) == 7 and all(0 <= s < 2 ** 62 for s in a)
+    assert ops._scope_base is None  # outside a scope every call draws from the generator again
+    torch.manual_seed(77)
+    outside = ops._fresh_seed()
+    torch.manual_seed(77)
+    assert ops._fresh_seed() == outside
