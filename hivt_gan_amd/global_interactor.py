@@ -43,6 +43,10 @@ class GlobalInteractorLayer(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim * 4), nn.ReLU(inplace=True), nn.Dropout(dropout),
                                  nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
 
+    def paired_layers(self):
+        """Layer pairs evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
+        return [(self.lin_k_node, self.lin_v_node), (self.lin_k_edge, self.lin_v_edge), (self.lin_hh, self.lin_self)]
+
     def forward(self, x: torch.Tensor, edge_index: Optional[torch.Tensor], edge_attr: torch.Tensor, size=None,
                 edges: Optional[EdgeSet] = None) -> torch.Tensor:
         """With ``edges`` given, ``edge_attr`` [E, D] is already in its CSR order; otherwise

@@ -80,6 +80,21 @@ class HiVT(nn.Module):
     def critics(self) -> Dict[str, nn.Module]:
         return {"short": self.D_short, "mid": self.D_mid, "long": self.D_long}
 
+    def pack_parameters(self) -> int:
+        """Lays the parameters of layer pairs that are evaluated as one product (K | V projections, the
+        two centre-row projections of the gated update) back to back in memory, so the step hands them
+        to the kernels without concatenating them first.  Values, names and ``state_dict`` are unchanged.
+        Call it with the model on its final device and before building optimizers; returns the number of
+        pairs packed."""
+        pairs = 0
+        for module in self.modules():
+            if hasattr(module, "paired_layers"):
+                for a, b in module.paired_layers():
+                    ops.pack_rows([a.weight, b.weight])
+                    ops.pack_rows([a.bias, b.bias])
+                    pairs += 1
+        return pairs
+
     def generator_parameters(self) -> List[nn.Parameter]:
         """Parameter order of the generator optimizer (``models/hivt.py:439-442``)."""
         return (list(self.local_encoder.parameters()) + list(self.global_interactor.parameters())

@@ -102,6 +102,8 @@ def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_sr
 
 def _fused_linear(x: torch.Tensor, a: nn.Linear, b: nn.Linear) -> torch.Tensor:
     """[a(x) | b(x)] as one product."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return ops.pair_linear(x, a, b)  # no copy of the parameters once they are packed (HiVT.pack_parameters)
     return ops.fused_linear(x, torch.cat([a.weight, b.weight], dim=0), torch.cat([a.bias, b.bias], dim=0))
 
 
@@ -149,6 +151,10 @@ class _EdgeAttentionBase(nn.Module):
         self.norm2 = nn.LayerNorm(embed_dim)
         self.mlp = nn.Sequential(nn.Linear(embed_dim, embed_dim * 4), nn.ReLU(inplace=True), nn.Dropout(dropout),
                                  nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
+
+    def paired_layers(self):
+        """Layer pairs evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
+        return [(self.lin_k, self.lin_v), (self.lin_hh, self.lin_self)]
 
     def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet,
                            residual: Optional[torch.Tensor] = None) -> torch.Tensor:

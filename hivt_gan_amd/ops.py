@@ -611,6 +611,88 @@ class _FusedLinear(torch.autograd.Function):
         return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres
 
 
+# --------------------------------------------------------------------------------------------
+# Two linear layers on the same input as one product, without copying their parameters
+# --------------------------------------------------------------------------------------------
+def pack_rows(params) -> None:
+    """Re-lays the given parameters (same trailing shape) back to back in one buffer.  Every parameter
+    keeps its identity, shape and values -- ``p.data`` becomes a view of the shared buffer -- so
+    optimizers, ``state_dict`` and in-place loads see no difference, while ``_stacked`` can hand the
+    row-wise concatenation of neighbours to a kernel without a copy.  Moving the module to another
+    device or dtype un-packs it again (every parameter gets storage of its own); the consumers then
+    fall back to a concatenation."""
+    params = list(params)
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+
+
+def _stacked(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``[a; b]`` along dim 0: a view when ``b`` starts where ``a`` ends in the same buffer (see
+    ``pack_rows``), a concatenation otherwise.  No autograd history either way."""
+    a, b = a.detach(), b.detach()
+    if (a.is_contiguous() and b.is_contiguous() and a.shape[1:] == b.shape[1:] and a.dtype == b.dtype
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        return torch.as_strided(a, (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+    return torch.cat([a, b], dim=0)
+
+
+class _PairLinear(torch.autograd.Function):
+    """``[x w_a^T + b_a | x w_b^T + b_b]``: one forward product, one data-gradient product and one
+    weight-gradient product for two layers that read the same rows."""
+
+    @staticmethod
+    def forward(ctx, x, w_a, b_a, w_b, b_b):
+        _need_gpu(x, w_a, w_b)
+        lead = x.shape[:-1]
+        x2 = _rows2(x)
+        m, k = x2.shape
+        if w_a.shape[1] != k or w_b.shape[1] != k:
+            raise ValueError(f"weights {tuple(w_a.shape)}, {tuple(w_b.shape)} do not match input width {k}")
+        w = _stacked(w_a, w_b)
+        b = _stacked(b_a, b_b)
+        n = w.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w), w.stride(0), _p(b), None, 0, None, 0, None, None, 0.0,
+                  EPI_NONE, 1.0, 0.0, 0, None, None, 0, m, n, k, _p(y), n, None, 0, None, _stream(x))
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (tuple(lead), int(w_a.shape[0]))
+        return y.view(*lead, n)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        lead, n_a = ctx.cfg
+        m, k = x2.shape
+        n = w.shape[0]
+        dev = x2.device
+        dy2 = _rows2(dy)
+        s = _stream(x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(m, k, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0, None, 0,
+                      _p(dx), k, s)
+            dx = dx.view(*lead, k)
+        dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+        db = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
+        _lib.call("hivt_linear_wgrad", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), m, n, k, _p(dw), _p(db), _p(ws),
+                  ws.numel(), s)
+        return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:]
+
+
+def pair_linear(x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear) -> torch.Tensor:
+    """``[a(x) | b(x)]`` as one product (GPU float32 tensors; both layers with a bias)."""
+    return _PairLinear.apply(x, a.weight, a.bias, b.weight, b.bias)
+
+
 class _LayerNorm(torch.autograd.Function):
     """``(y, x_again)``: the normalised rows and the input handed back as a second output.  A pre-norm
     block ``x + block(norm(x))`` takes its residual operand from ``x_again``; autograd then delivers
@@ -1247,8 +1329,8 @@ class _GatedUpdateTail(torch.autograd.Function):
         dev = agg.device
         st = _stream(agg)
         agg2, c2, r2 = _rows2(agg), _rows2(center), _rows2(res)
-        w_hs = torch.cat([w_hh, w_self], dim=0)
-        b_hs = torch.cat([b_hh, b_self], dim=0)
+        w_hs = _stacked(w_hh, w_self)
+        b_hs = _stacked(b_hh, b_self)
         w_ih_c, w_out_c, b_ih_c, b_out_c = _rows2(w_ih), _rows2(w_out), b_ih.contiguous(), b_out.contiguous()
         ih = torch.empty(n, d, dtype=torch.float32, device=dev)
         hs = torch.empty(n, 2 * d, dtype=torch.float32, device=dev)

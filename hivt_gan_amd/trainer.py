@@ -104,6 +104,8 @@ class GanTrainer:
             if not next(model.parameters()).is_cuda:
                 raise RuntimeError("the read-back-free step needs the model on the GPU")
             model.sync_free = True
+        if next(model.parameters()).is_cuda:
+            model.pack_parameters()  # before the optimizers take hold of the parameters
         opts, scheds = model.configure_optimizers()
         self.opt_g = opts[0]
         self.opt_d = opts[1] if len(opts) > 1 else None

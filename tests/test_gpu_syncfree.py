@@ -274,3 +274,63 @@ def test_cached_list_adamw_equals_the_stock_fused_adamw():
             assert torch.equal(sa[key], sb[key]), key
     assert opt_a._lists is not None and float(opt_a.state[mine[0]]["step"]) == 6.0
     assert opt_a.state_dict()["param_groups"] == opt_b.state_dict()["param_groups"]
+
+
+def test_packed_parameters_change_nothing_but_the_copies():
+    """``HiVT.pack_parameters`` lays paired layers back to back: the kernels then read [a; b] in place.
+    Outputs and every gradient equal the unpacked model's bit for bit; an optimizer step, an in-place
+    ``load_state_dict`` keep the layout; moving the module un-packs it and the step still works."""
+    import hivt_gan_amd as hv
+    from hivt_gan_amd import ops
+    torch.manual_seed(5)
+    cfg = dict(embed_dim=64, num_heads=8, dropout=0.0, num_temporal_layers=1, num_global_layers=2, use_gan=False,
+               rotate=True)
+    plain = hv.HiVT(**cfg).to("cuda:0")
+    packed = hv.HiVT(**cfg).to("cuda:0")
+    packed.load_state_dict(plain.state_dict())
+    assert packed.pack_parameters() == 2 * 2 + 2 * 3
+
+    def is_view(a, b):
+        w = ops._stacked(a.weight, b.weight)
+        return w.data_ptr() == a.weight.data_ptr() and w.shape[0] == a.weight.shape[0] + b.weight.shape[0]
+
+    layer = packed.global_interactor.global_interactor_layers[0]
+    aa = packed.local_encoder.aa_encoder
+    assert is_view(layer.lin_k_node, layer.lin_v_node) and is_view(layer.lin_hh, layer.lin_self)
+    assert is_view(aa.lin_k, aa.lin_v)
+    assert not is_view(plain.local_encoder.aa_encoder.lin_k, plain.local_encoder.aa_encoder.lin_v)
+
+    def run(model):
+        batch = hv.make_batch(3, first_index=40).to("cuda:0")
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        y_hat, pi = model(batch)
+        (y_hat.square().mean() + pi.square().mean()).backward()
+        return y_hat.detach(), pi.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    y0, pi0, g0 = run(plain)
+    y1, pi1, g1 = run(packed)
+    assert torch.equal(y0, y1) and torch.equal(pi0, pi1)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+    # an optimizer step and an in-place load keep the neighbours adjacent
+    (opt,), _ = packed.configure_optimizers()
+    opt.step()
+    assert is_view(aa.lin_k, aa.lin_v)
+    packed.load_state_dict(plain.state_dict())
+    assert is_view(aa.lin_k, aa.lin_v) and torch.equal(aa.lin_v.weight, plain.local_encoder.aa_encoder.lin_v.weight)
+    y2, _, g2 = run(packed)
+    assert torch.equal(y2, y0) and all(torch.equal(g2[k], g0[k]) for k in g0)
+
+    # state_dict of a packed model holds plain tensors of the usual shapes
+    sd = packed.state_dict()
+    assert sd["local_encoder.aa_encoder.lin_v.weight"].shape == (64, 64)
+
+    # moving the module gives every parameter its own storage again: the concatenating path takes over
+    moved = packed.cpu().to("cuda:0")
+    assert not is_view(moved.local_encoder.aa_encoder.lin_k, moved.local_encoder.aa_encoder.lin_v)
+    y3, _, g3 = run(moved)
+    assert torch.equal(y3, y0) and all(torch.equal(g3[k], g0[k]) for k in g0)
