@@ -10,6 +10,7 @@ The sparse arithmetic runs in hand-written gfx950 kernels reached through ``libh
 """
 from .critics import BaseTrajectoryCritic, LongScaleCritic, MidScaleCritic, ShortScaleCritic
 from .data import BatchSpec, TemporalData, collate, make_batch, make_scene, pad_batch
+from .dataset import SceneDataset, batches, load_scene, sanitize, save_scene
 from .decoder import MLPDecoder
 from .embedding import MultipleInputEmbedding, SingleInputEmbedding, init_weights
 from .global_interactor import GlobalInteractor, GlobalInteractorLayer
@@ -28,5 +29,5 @@ __all__ = [
     "R1Regularization", "AdversarialDiscriminatorLoss", "AdversarialGeneratorLoss", "fused_supervised_losses", "HiVT",
     "TemporalData", "collate", "make_scene", "make_batch", "DistanceDropEdge", "EdgePlan", "build_edge_plan",
     "subgraph", "init_weights", "GanTrainer", "BatchSpec", "pad_batch", "ADE", "FDE", "MR", "Jerk", "SpeedViolation",
-    "EndpointDiversity", "ValidationMetrics",
+    "EndpointDiversity", "ValidationMetrics", "SceneDataset", "batches", "load_scene", "save_scene", "sanitize",
 ]
