@@ -39,10 +39,10 @@ from hivt_gan_amd import ops  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 
 
-def model_config(embed_dim: int):
+def model_config(embed_dim: int, local_radius: float = 50.0):
     return dict(historical_steps=20, future_steps=30, num_modes=6, rotate=True, node_dim=2, edge_dim=2,
                 embed_dim=embed_dim, num_heads=8, dropout=0.1, num_temporal_layers=4, num_global_layers=3,
-                local_radius=50.0, parallel=False, lr=5e-4, weight_decay=1e-4, T_max=64, use_gan=True,
+                local_radius=local_radius, parallel=False, lr=5e-4, weight_decay=1e-4, T_max=64, use_gan=True,
                 lambda_adv=0.1, lambda_r1=1.0, critic_steps=1, short_horizon=10, mid_horizon=20, critic_lr=1e-4)
 
 
@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--embed-dim", type=int, default=128)
     ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
+    ap.add_argument("--dense", action="store_true",
+                    help="dense-scene stress shape instead of the headline workload: 200 agents and 1000 lane "
+                         "segments per scene, 150 m radius, every step valid (use with --scenes 2..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--matmul", choices=("fp32", "bf16"), default="bf16",
                     help="operand precision of the dense products: bf16 operands with fp32 accumulation (the named "
@@ -157,13 +160,14 @@ def main():
 
     ops.set_matmul_precision(args.matmul)
     torch.manual_seed(2022)
-    model = hv.HiVT(**model_config(args.embed_dim)).to(dev)
+    scene_kwargs = dict(num_agents=200, num_lanes=1000, all_valid=True, local_radius=150.0) if args.dense else {}
+    model = hv.HiVT(**model_config(args.embed_dim, 150.0 if args.dense else 50.0)).to(dev)
     model.train()
 
     # synthetic batches, resident in HBM before the timed region; distinct scenes per rank
     pool = []
     for i in range(args.pool):
-        b = hv.make_batch(args.scenes, first_index=(rank * args.pool + i) * args.scenes).to(dev)
+        b = hv.make_batch(args.scenes, first_index=(rank * args.pool + i) * args.scenes, **scene_kwargs).to(dev)
         pool.append((b, b["y"]))
     # capacities of the filtered edge lists, measured once over the pool with 10 % head room: with them
     # the step needs no host read-back (live counts, guards and the overflow flag stay on the device)
@@ -241,7 +245,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.matmul == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"HiVT-{args.embed_dim} full G+D+R1 train step, {args.scenes} synthetic "
-                                   f"nuScenes-shaped scenes per GPU per step, dropout 0.1, AdamW x2, "
+                                   + ("dense (200 agents, 1000 lane segments, 150 m radius) " if args.dense else
+                                      "nuScenes-shaped ")
+                                   + "scenes per GPU per step, dropout 0.1, AdamW x2, "
                                    + ("bf16 dense products" if args.matmul == "bf16" else "fp32"),
                        "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
                        "guards": "host" if args.host_guards else "device",
