@@ -64,6 +64,11 @@ struct Stage {
   static constexpr int PITCH_H = kBK + 4;  // halves per row of the bf16 image
   static constexpr int FLOATS = BF16 ? ROWS * PITCH_H / 2 : kBK * PITCH;  // LDS floats of one staged step
   static constexpr int NVEC = ROWS * kBK / 4 / kThreads;  // float4 per thread per step
+  // bf16 image of a row-major operand (reduction index strided): a thread owns pieces (2q, 2q + 1) = two
+  // consecutive reduction indices of the same four rows, so the rounded values leave as four 32-bit
+  // stores per pair instead of eight 16-bit ones
+  static constexpr bool PAIRED = BF16 && !TRANS;
+  static_assert(!PAIRED || NVEC % 2 == 0, "paired staging needs an even number of pieces");
   float4 v[NVEC];
   unsigned ok;  // 4 validity bits per float4; applied when the values are written to LDS
   float4 colsum = {0.f, 0.f, 0.f, 0.f};  // ACCUM: running sum of everything this thread staged
@@ -79,6 +84,10 @@ struct Stage {
       if (TRANS) {
         row = idx / (kBK / 4);
         red = (idx % (kBK / 4)) * 4;
+      } else if (PAIRED) {
+        const int pair = tid + (r >> 1) * kThreads;
+        red = 2 * (pair / (ROWS / 4)) + (r & 1);
+        row = (pair % (ROWS / 4)) * 4;
       } else {
         red = idx / (ROWS / 4);
         row = (idx % (ROWS / 4)) * 4;
@@ -112,7 +121,38 @@ struct Stage {
   }
 
   // One float4 of the staged step (r < NVEC) goes to LDS; store() sends all of them.
+  __device__ __forceinline__ float4 masked(int r) const {
+    const unsigned m = ok >> (4 * r);
+    float4 val;
+    val.x = (m & 1u) ? v[r].x : 0.0f;
+    val.y = (m & 2u) ? v[r].y : 0.0f;
+    val.z = (m & 4u) ? v[r].z : 0.0f;
+    val.w = (m & 8u) ? v[r].w : 0.0f;
+    return val;
+  }
+
   __device__ __forceinline__ void store_piece(float* lds, int tid, int r) {
+    if constexpr (PAIRED) {
+      if ((r & 1) == 0) return;  // leaves together with its odd neighbour
+      const float4 lo = masked(r - 1), hi = masked(r);
+      if (ACCUM) {
+        colsum.x += lo.x + hi.x;
+        colsum.y += lo.y + hi.y;
+        colsum.z += lo.z + hi.z;
+        colsum.w += lo.w + hi.w;
+      }
+      const f32x4 fl = {lo.x, lo.y, lo.z, lo.w}, fh = {hi.x, hi.y, hi.z, hi.w};
+      const s16x4 bl = __builtin_bit_cast(s16x4, __builtin_convertvector(fl, bf16x4));
+      const s16x4 bh = __builtin_bit_cast(s16x4, __builtin_convertvector(fh, bf16x4));
+      const int pair = tid + (r >> 1) * kThreads;
+      const int red = 2 * (pair / (ROWS / 4));
+      const int row = (pair % (ROWS / 4)) * 4;
+      unsigned* image = reinterpret_cast<unsigned*>(lds);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        image[((row + i) * PITCH_H + red) / 2] = (unsigned)(unsigned short)bl[i] | ((unsigned)(unsigned short)bh[i] << 16);
+      return;
+    }
     const int idx = tid + r * kThreads;
     const unsigned m = ok >> (4 * r);
     float4 val;
@@ -129,20 +169,11 @@ struct Stage {
     if (BF16) {
       const f32x4 f = {val.x, val.y, val.z, val.w};
       const bf16x4 h = __builtin_convertvector(f, bf16x4);
+      // TRANS (the other layout took the paired path above): four consecutive k of one row, one 8-byte store
       unsigned short* image = reinterpret_cast<unsigned short*>(lds);
-      if (TRANS) {  // four consecutive k of one row: one 8-byte store
-        const int row = idx / (kBK / 4);
-        const int red = (idx % (kBK / 4)) * 4;
-        *reinterpret_cast<bf16x4*>(image + row * PITCH_H + red) = h;
-      } else {      // one k of four consecutive rows
-        const int red = idx / (ROWS / 4);
-        const int row = (idx % (ROWS / 4)) * 4;
-        const s16x4 bits = __builtin_bit_cast(s16x4, h);
-        image[(row + 0) * PITCH_H + red] = (unsigned short)bits[0];
-        image[(row + 1) * PITCH_H + red] = (unsigned short)bits[1];
-        image[(row + 2) * PITCH_H + red] = (unsigned short)bits[2];
-        image[(row + 3) * PITCH_H + red] = (unsigned short)bits[3];
-      }
+      const int row = idx / (kBK / 4);
+      const int red = (idx % (kBK / 4)) * 4;
+      *reinterpret_cast<bf16x4*>(image + row * PITCH_H + red) = h;
     } else if (TRANS) {
       const int row = idx / (kBK / 4);
       const int red = (idx % (kBK / 4)) * 4;
