@@ -3,13 +3,21 @@
 ``torch.optim.AdamW(fused=True)`` rebuilds its tensor lists from ``param_groups`` and ``state`` on every
 call and advances one step counter per parameter (several hundred microseconds of host time and a
 dozen small launches for a few hundred parameters).  ``FusedAdamW`` is the same optimizer (same state
-layout, ``state_dict``, schedulers, ``found_inf`` / ``grad_scale`` attributes, same multi-tensor update
-kernel) that keeps those lists between calls and lets the parameters of a group share ONE step counter
-while their counts agree.  Whenever the set of parameters holding a gradient differs from the cached
-one, and whenever the state is exported or replaced, it returns to the stock layout and ``step``."""
+layout, ``state_dict``, schedulers, ``found_inf`` / ``grad_scale`` attributes) that keeps those lists
+between calls and lets the parameters of a group share ONE step counter while their counts agree.
+Whenever the set of parameters holding a gradient differs from the cached one, and whenever the state is
+exported or replaced, it returns to the stock layout and ``step``.  The arithmetic of a cached step runs
+in the library's own multi-tensor kernel (``hivt_adamw_step``; same formula, results equal to the
+framework's to rounding); ``use_library_kernel = False`` keeps the framework's kernel."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
+
+from . import _lib
+
+_DATA_PTR = torch.Tensor.data_ptr
 
 
 class FusedAdamW(torch.optim.AdamW):
@@ -18,6 +26,9 @@ class FusedAdamW(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
         # per group: (params with a gradient, the rest, exp_avgs, exp_avg_sqs, step list, shared step or None)
         self._lists = None
+        self.use_library_kernel = True
+        self._library_meta = {}  # id(list of params) -> host arrays of state addresses and sizes
+        self.library_steps = 0   # group updates that went through the library's kernel
 
     # -- cache management -------------------------------------------------------------------------
     def _untie(self) -> None:
@@ -30,6 +41,7 @@ class FusedAdamW(torch.optim.AdamW):
         self._lists = None
 
     def _cache(self) -> None:
+        self._library_meta = {}
         lists = []
         for group in self.param_groups:
             params = [p for p in group["params"] if p.grad is not None]
@@ -75,6 +87,38 @@ class FusedAdamW(torch.optim.AdamW):
                 p.grad = None
 
     # -- the update ---------------------------------------------------------------------------------
+    def _library_step(self, group, params, grads, exp_avgs, exp_avg_sqs, step, found_inf) -> bool:
+        """The update of one group through ``hivt_adamw_step`` (up to 96 tensors per launch, 4096-element
+        pieces) instead of the framework's multi-tensor kernel, whose 65 536-element pieces leave a few
+        hundred small tensors with a handful of busy workgroups per launch.  False: not applicable here
+        (the caller then runs the framework's kernel)."""
+        if not self.use_library_kernel or not isinstance(group["lr"], float) or step.dtype != torch.float32:
+            return False
+        for g in grads:
+            if not g.is_contiguous() or g.dtype != torch.float32:
+                return False
+        if found_inf is not None and (found_inf.dtype != torch.float32 or not found_inf.is_cuda):
+            return False
+        count = len(params)
+        meta = self._library_meta.get(id(params))
+        if meta is None or meta[0] is not params:
+            for t in params + exp_avgs + exp_avg_sqs:
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    return False
+            array = ctypes.c_uint64 * count
+            meta = (params, array, array(*[t.data_ptr() for t in exp_avgs]), array(*[t.data_ptr() for t in exp_avg_sqs]),
+                    (ctypes.c_int64 * count)(*[p.numel() for p in params]))
+            self._library_meta[id(params)] = meta
+        _, array, m_ptrs, v_ptrs, numels = meta
+        beta1, beta2 = group["betas"]
+        # parameter addresses are read every time: a parameter's storage may have been replaced since
+        _lib.call("hivt_adamw_step", array(*map(_DATA_PTR, params)), array(*map(_DATA_PTR, grads)), m_ptrs, v_ptrs,
+                  numels, count, step.data_ptr(), found_inf.data_ptr() if found_inf is not None else None,
+                  group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                  torch.cuda.current_stream(params[0].device).cuda_stream)
+        self.library_steps += 1
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         lists = self._lists
@@ -108,9 +152,12 @@ class FusedAdamW(torch.optim.AdamW):
                         shared.add_(1)
                     else:
                         torch._foreach_add_(steps, 1)
-                    torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
-                                        lr=group["lr"], beta1=beta1, beta2=beta2, weight_decay=group["weight_decay"],
-                                        eps=group["eps"], maximize=False, grad_scale=grad_scale, found_inf=found_inf)
+                    if not (shared is not None and grad_scale is None and self._library_step(
+                            group, params, grads, exp_avgs, exp_avg_sqs, shared, found_inf)):
+                        torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
+                                            lr=group["lr"], beta1=beta1, beta2=beta2,
+                                            weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
+                                            grad_scale=grad_scale, found_inf=found_inf)
                     if found_inf is not None:  # a skipped update does not count as a step
                         if shared is not None:
                             shared.sub_(found_inf.to(shared.dtype).view(()))

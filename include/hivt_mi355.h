@@ -432,6 +432,19 @@ int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_f
                       const float* count, int64_t B, float lambda_r1, float* g_real, float* g_norm2, float* g_fake,
                       hivt_stream_t stream);
 
+/* AdamW update of `count` float32 tensors (torch.optim.AdamW as the reference configures it,
+ * models/hivt.py:444,453: decoupled weight decay, no amsgrad):
+ *   p *= 1 - lr * weight_decay;  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * params / grads / exp_avgs / exp_avg_sqs are HOST arrays of `count` device addresses, numels the element
+ * counts; `step` is a device scalar holding the number of this update (>= 1, advanced by the caller);
+ * found_inf (optional device scalar) == 1 leaves every tensor untouched.  Up to 96 tensors travel in one
+ * launch's argument block, cut into 4096-element pieces, one workgroup each. */
+int hivt_adamw_step(const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
+                    const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, const float* step,
+                    const float* found_inf, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    hivt_stream_t stream);
+
 /* Generator's adversarial term of one scale (losses/adv_losses.py:91-98): out = scale * sum_i w_i s_i / count
  * (scale = -1 for -mean D(fake)), and its gradient g_s_i = scale * g_out * w_i / count. */
 int hivt_weighted_mean_fwd(const float* s, const float* w, const float* count, int64_t B, float scale, float* out,
