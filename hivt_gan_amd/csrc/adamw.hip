@@ -45,15 +45,36 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamBatch a) {
   const float bc2_sqrt = sqrtf(1.0f - powf(a.beta2, step));
   const float step_size = a.lr / bc1;
   const float decay = 1.0f - a.lr * a.weight_decay;
-  for (int i = begin + threadIdx.x; i < end; i += 256) {
-    const float grad = g[i];
-    const float param = p[i] * decay;
-    const float mi = a.beta1 * m[i] + (1.0f - a.beta1) * grad;
-    const float vi = a.beta2 * v[i] + (1.0f - a.beta2) * grad * grad;
+  auto update = [&](float& pi, float grad, float& mi, float& vi) {
+    const float param = pi * decay;
+    mi = a.beta1 * mi + (1.0f - a.beta1) * grad;
+    vi = a.beta2 * vi + (1.0f - a.beta2) * grad * grad;
     const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    pi = param - step_size * (mi / denom);
+  };
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                         reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v);
+  if ((bits & 15) == 0 && (n & 3) == 0) {  // whole tensor in 16-byte quads (pieces start at multiples of 4096)
+    for (int i = begin + 4 * threadIdx.x; i < end; i += 4 * 256) {
+      float4 p4 = *reinterpret_cast<float4*>(p + i), m4 = *reinterpret_cast<float4*>(m + i);
+      float4 v4 = *reinterpret_cast<float4*>(v + i);
+      const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+      update(p4.x, g4.x, m4.x, v4.x);
+      update(p4.y, g4.y, m4.y, v4.y);
+      update(p4.z, g4.z, m4.z, v4.z);
+      update(p4.w, g4.w, m4.w, v4.w);
+      *reinterpret_cast<float4*>(m + i) = m4;
+      *reinterpret_cast<float4*>(v + i) = v4;
+      *reinterpret_cast<float4*>(p + i) = p4;
+    }
+    return;
+  }
+  for (int i = begin + threadIdx.x; i < end; i += 256) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    update(pi, g[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
-    p[i] = param - step_size * (mi / denom);
+    p[i] = pi;
   }
 }
 
