@@ -46,17 +46,22 @@ def model_config(embed_dim: int, local_radius: float = 50.0):
                 lambda_adv=0.1, lambda_r1=1.0, critic_steps=1, short_horizon=10, mid_horizon=20, critic_lr=1e-4)
 
 
-def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool) -> float:
-    """Algorithmic HBM bytes of one launch (fp32 rows, int32 CSR)."""
+def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool, n_live: int = None) -> float:
+    """Algorithmic HBM bytes of one launch (fp32 rows, int32 CSR).  ``n_live`` = target rows with at
+    least one edge: a row without edges needs neither its query nor (backward) its output / output
+    gradient, and the kernels skip those loads, so they are not credited."""
     s = 4
+    n_live = n if n_live is None else n_live
     if kind == "fwd":
-        b = e * (2 * d * s + 4) + n * (2 * d * s + 4) + n * h * 8
+        # K, V rows (+ source ids); rowptr; q of live rows; out + saved max / denominator of every row
+        b = e * 2 * d * s + n * 4 + n_live * d * s + n * d * s + n * h * 8
         if node_terms:
             b += n * 2 * d * s + e * 4
     else:
-        b = e * (4 * d * s + 4) + n * (4 * d * s + 4)
+        # K, V read, dK, dV written; rowptr; q, out, d_out (+ max / denominator) of live rows; dq of every row
+        b = e * 4 * d * s + n * 4 + n_live * (3 * d * s + h * 8) + n * d * s
         if node_terms:
-            b += n * 4 * d * s + e * 4
+            b += n * 2 * d * s + e * 4
     return float(b)
 
 
@@ -222,23 +227,29 @@ def main():
 
     if rank == 0:
         groups = {}
-        for kind, tag, n, live, d, h, node_terms, ev0, ev1 in records:
-            groups.setdefault((kind, tag, node_terms, d, h), []).append((n, int(live.item()),
-                                                                         ev0.elapsed_time(ev1) * 1e-3))
+        for kind, tag, n, rowptr, d, h, node_terms, ev0, ev1 in records:
+            rp = rowptr.cpu()
+            groups.setdefault((kind, tag, node_terms, d, h), []).append(
+                (n, int(rp[n]), ev0.elapsed_time(ev1) * 1e-3, int((rp[1:] > rp[:-1]).sum())))
         roofline, extra = None, []
         traffic = measured_traffic(args.embed_dim, args.scenes)
         for (kind, tag, node_terms, d, h), rows in groups.items():
-            by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms) for n, e, _ in rows) / len(rows)
+            by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms, live) for n, e, _, live in rows) / len(rows)
             tm = sum(r[2] for r in rows) / len(rows)
             entry = {"kernel": f"seg_attn_{kind}_kernel", "caller": tag, "bound": "hbm", "achieved": by / tm / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / tm / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get(f"{kind}/{tag}"),
                      "bytes_per_launch": by, "avg_launch_us": tm * 1e6, "launches": len(rows),
                      "edges_per_launch": sum(r[1] for r in rows) / len(rows),
-                     "rows_per_launch": sum(r[0] for r in rows) / len(rows)}
+                     "rows_per_launch": sum(r[0] for r in rows) / len(rows),
+                     "rows_with_edges_per_launch": sum(r[3] for r in rows) / len(rows)}
+            entry["us_per_step"] = tm * 1e6 * len(rows) / args.steps
             extra.append(entry)
-            # dominant kernel: the forward over all 20 timesteps' agent-agent edges (most bytes per step)
-            if kind == "fwd" and tag == "AAEncoder":
-                roofline = entry
+        # dominant kernel = the edge-attention launch kind that takes the most time per step
+        if extra:
+            roofline = dict(max(extra, key=lambda en: en["us_per_step"]))
+            tot_b = sum(en["bytes_per_launch"] * en["launches"] for en in extra)
+            tot_t = sum(en["avg_launch_us"] * 1e-6 * en["launches"] for en in extra)
+            roofline["all_kinds_time_weighted_frac"] = tot_b / tot_t / 1e9 / HBM_PEAK_GBS
         result = {
             "metric": "train scenes/sec (G+D+R1 step)", "value": world * args.scenes * args.steps / elapsed,
             "unit": "scenes/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -207,9 +207,11 @@ class HiVT(nn.Module):
     def _training_step_guarded(self, data, opt_g, opt_d, sync_grads) -> Dict[str, torch.Tensor]:
 
         def skip(reason: str) -> Dict[str, torch.Tensor]:
-            # zero-gradient participation keeps data-parallel ranks in lock-step
-            for group, opt in (("critic", opt_d), ("generator", opt_g)):
-                if opt is None or (group == "critic" and not self.use_gan):
+            # zero-gradient participation keeps data-parallel ranks in lock-step: the same sequence of
+            # collectives as a healthy rank -- critic_steps critic reductions, then the generator's
+            schedule = [("critic", opt_d)] * (self.critic_steps if self.use_gan else 0) + [("generator", opt_g)]
+            for group, opt in schedule:
+                if opt is None:
                     continue
                 if sync_grads is not None:
                     # the other ranks step with the averaged gradient; so must this one, or the

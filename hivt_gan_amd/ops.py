@@ -241,10 +241,10 @@ def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, sr
 # Kernels (b)+(c): segment softmax attention
 # --------------------------------------------------------------------------------------------
 # When set to a list, every segment-attention launch appends
-# (kind, tag, rows, live_edges, D, H, has_node_terms, start_event, end_event) -- events carrying the
-# kernel's own start / stop time stamps, and the live edge count as a one-element device view of
-# rowptr (fixed-capacity lists hold fewer edges than rows of K|V) -- so a benchmark can price the
-# kernel inside a real step.
+# (kind, tag, rows, rowptr, D, H, has_node_terms, start_event, end_event) -- events carrying the
+# kernel's own start / stop time stamps, and the launch's rowptr (device tensor: fixed-capacity lists
+# hold fewer live edges than rows of K|V, and rows without edges move fewer bytes) -- so a benchmark can
+# price the kernel inside a real step.
 SEG_ATTN_TIMING = None
 
 
@@ -327,7 +327,7 @@ class _SegAttn(torch.autograd.Function):
         m = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         den = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _timed_call("fwd", tag, n, rowptr[n:n + 1], d_model, num_heads, kv_node is not None, q.device,
+        _timed_call("fwd", tag, n, rowptr, d_model, num_heads, kv_node is not None, q.device,
                     "hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
@@ -349,7 +349,7 @@ class _SegAttn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty(e, 2 * d_model, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
-        _timed_call("bwd", tag, n, rowptr[n:n + 1], d_model, num_heads, kv_node is not None, q.device,
+        _timed_call("bwd", tag, n, rowptr, d_model, num_heads, kv_node is not None, q.device,
                     "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
