@@ -24,6 +24,7 @@ SIGNATURES = {
     "hivt_edges_radius": (c_int, [_P, c_int64, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_csr_build": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_csr_build_static": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P]),
     "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
     "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),

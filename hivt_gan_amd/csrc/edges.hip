@@ -7,6 +7,8 @@
 // fixes the CSR order and therefore the floating-point accumulation order downstream.
 #include "common.h"
 
+#include <mutex>
+
 namespace hivt {
 namespace {
 
@@ -315,19 +317,10 @@ extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {
          align_up((size_t)(E > 0 ? E : 1) * sizeof(int32_t), 256);
 }
 
-extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
-                              int32_t* rowptr, int32_t* perm, void* workspace, size_t workspace_bytes,
-                              hivt_stream_t stream_) {
-  const char* what = "hivt_csr_build";
-  hipStream_t stream = (hipStream_t)stream_;
-  HIVT_REQUIRE(E >= 0 && E < (int64_t)1 << 31 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
-  HIVT_REQUIRE(rowptr != nullptr, HIVT_ERR_ARG, "%s: rowptr is null", what);
-  HIVT_REQUIRE(E == 0 || (key && perm), HIVT_ERR_ARG, "%s: null pointer", what);
-  HIVT_REQUIRE(workspace != nullptr && workspace_bytes >= hivt_csr_workspace_bytes(E, num_rows), HIVT_ERR_WORKSPACE,
-               "%s: workspace too small (%zu < %zu)", what, workspace_bytes, hivt_csr_workspace_bytes(E, num_rows));
-  int32_t* cursor = reinterpret_cast<int32_t*>(workspace);
-  int32_t* tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) +
-                                            align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256));
+// Launch sequence shared by hivt_csr_build and hivt_csr_build_static: `cursor` (num_rows words) and `tmp`
+// (E words) are the scratch the kernels need; both are fully (re)initialised here before use.
+static int csr_build_launch(const char* what, const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
+                            int32_t* rowptr, int32_t* perm, int32_t* cursor, int32_t* tmp, hipStream_t stream) {
   // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
   zero_words(cursor, num_rows > 0 ? num_rows : 1, stream);
   HIVT_CHECK_LAUNCH(what);
@@ -350,6 +343,62 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* coun
     HIVT_CHECK_LAUNCH(what);
   }
   return HIVT_OK;
+}
+
+extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
+                              int32_t* rowptr, int32_t* perm, void* workspace, size_t workspace_bytes,
+                              hivt_stream_t stream_) {
+  const char* what = "hivt_csr_build";
+  hipStream_t stream = (hipStream_t)stream_;
+  HIVT_REQUIRE(E >= 0 && E < (int64_t)1 << 31 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(rowptr != nullptr, HIVT_ERR_ARG, "%s: rowptr is null", what);
+  HIVT_REQUIRE(E == 0 || (key && perm), HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(workspace != nullptr && workspace_bytes >= hivt_csr_workspace_bytes(E, num_rows), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small (%zu < %zu)", what, workspace_bytes, hivt_csr_workspace_bytes(E, num_rows));
+  int32_t* cursor = reinterpret_cast<int32_t*>(workspace);
+  int32_t* tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) +
+                                            align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256));
+  return csr_build_launch(what, key, E, count, num_rows, rowptr, perm, cursor, tmp, stream);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------
+// The CSR build's scratch (row cursors + unordered placement) lives in a file-scope device array, so
+// a caller that may not allocate (graph capture, a serving loop) needs no workspace.  Host code never
+// uses the array's name as an address: each device's copy is looked up once with
+// hipGetSymbolAddress and the kernels receive that pointer.
+static __device__ __align__(256) int32_t scratch[HIVT_CSR_STATIC_MAX_ROWS + HIVT_CSR_STATIC_MAX_EDGES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+int32_t* g_scratch_ptr[kMaxDevices] = {};  // per device: address of that device's `scratch`
+}  // namespace
+
+extern "C" int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
+                                     int32_t* rowptr, int32_t* perm, hivt_stream_t stream_) {
+  const char* what = "hivt_csr_build_static";
+  hipStream_t stream = (hipStream_t)stream_;
+  HIVT_REQUIRE(E >= 0 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(E <= HIVT_CSR_STATIC_MAX_EDGES && num_rows <= HIVT_CSR_STATIC_MAX_ROWS, HIVT_ERR_ARG,
+               "%s: E=%lld / num_rows=%d exceed the static scratch (%d edges, %d rows); use hivt_csr_build with a "
+               "workspace", what, (long long)E, num_rows, HIVT_CSR_STATIC_MAX_EDGES, HIVT_CSR_STATIC_MAX_ROWS);
+  HIVT_REQUIRE(rowptr != nullptr, HIVT_ERR_ARG, "%s: rowptr is null", what);
+  HIVT_REQUIRE(E == 0 || (key && perm), HIVT_ERR_ARG, "%s: null pointer", what);
+  int dev = -1;
+  HIVT_CHECK_HIP(hipGetDevice(&dev), what);
+  HIVT_REQUIRE(dev >= 0 && dev < kMaxDevices, HIVT_ERR_ARG, "%s: device ordinal %d out of range", what, dev);
+  int32_t* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+      void* p = nullptr;
+      HIVT_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)), what);
+      HIVT_REQUIRE(p != nullptr, HIVT_ERR_LAUNCH, "%s: the scratch symbol has no address on device %d", what, dev);
+      g_scratch_ptr[dev] = reinterpret_cast<int32_t*>(p);
+    }
+    base = g_scratch_ptr[dev];
+  }
+  return csr_build_launch(what, key, E, count, num_rows, rowptr, perm, base, base + HIVT_CSR_STATIC_MAX_ROWS, stream);
 }
 
 extern "C" int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,

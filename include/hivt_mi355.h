@@ -89,6 +89,19 @@ size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows);
 int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,
                    int32_t* perm, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
+/* hivt_csr_build without a workspace and without any allocation: the scratch (row cursors and the
+ * unordered placement) is a static device array inside the library, HIVT_CSR_STATIC_MAX_ROWS +
+ * HIVT_CSR_STATIC_MAX_EDGES int32 words (8 MiB) held on every GPU the library runs on until the process
+ * ends.  No counterpart in the reference: it exists for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same results
+ * as hivt_csr_build.  Sizes beyond the maxima are rejected with HIVT_ERR_ARG.  The device must be
+ * current and own `stream`.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race; calls on one stream are ordered and safe. */
+#define HIVT_CSR_STATIC_MAX_EDGES (1 << 20)
+#define HIVT_CSR_STATIC_MAX_ROWS (1 << 20)
+int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,
+                          int32_t* perm, hivt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Kernel (a): edge gather + rotation into the target's frame
  * ------------------------------------------------------------------------------------------ */
