@@ -1027,8 +1027,8 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
 
 using namespace hivt;
 
-extern "C" int hivt_set_matmul_bf16(int enable) {
-  return g_matmul_bf16.exchange(enable != 0 ? 1 : 0, std::memory_order_relaxed);
+extern "C" int hivt_set_matmul_bf16(int mask) {
+  return g_matmul_bf16.exchange(mask & (HIVT_BF16_FWD | HIVT_BF16_DGRAD | HIVT_BF16_WGRAD), std::memory_order_relaxed);
 }
 
 #ifdef HIVT_PROBE
@@ -1077,7 +1077,7 @@ static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
-  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
+  const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_FWD) != 0;
   // grids that leave compute units with a single workgroup get the deep-prefetch variant
 #define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
   if (vec && bf16) /* bf16 forward: the deep-prefetch variant wins at every grid size (13-20 % on large ones) */ \
@@ -1140,7 +1140,7 @@ static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, 
   a.add = add; a.add_ld = add_ld;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
-  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
+  const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_DGRAD) != 0;
   if (K <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), 1);
     if (vec && bf16 && grid.x <= kSmallGrid)
@@ -1232,7 +1232,7 @@ static int linear_wgrad_impl(const float* dy, int64_t dy_ld, const float* x, int
   a.bias_partial = dbias ? a.partial + (size_t)N * K : nullptr;
   a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
-  const bool bf16 = g_matmul_bf16.load(std::memory_order_relaxed) != 0;
+  const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_WGRAD) != 0;
   if (a.dy.vec_ok && a.x.vec_ok && bf16 && grid.x * grid.y * grid.z <= kSmallGrid)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, true>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok && bf16)

@@ -500,13 +500,22 @@ def _pass_through_grad(dy: torch.Tensor, shape, to_leaf: bool) -> torch.Tensor:
     return g.clone() if to_leaf else g
 
 
+_PRECISIONS = {"fp32": 0, "bf16": 7, "bf16-fwd": 1, "bf16-fwd-dgrad": 3}
+
+
 def set_matmul_precision(precision: str) -> str:
-    """``"fp32"`` (default: exact fp32 products) or ``"bf16"`` (operands of every dense product rounded to
-    bfloat16, fp32 accumulation; results within about 1e-2 of the fp32 ones).  Process-wide switch of the
-    library; returns the previous setting."""
-    if precision not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
-    return "bf16" if _lib.value("hivt_set_matmul_bf16", 1 if precision == "bf16" else 0) else "fp32"
+    """Operand precision of the dense products, process-wide; returns the previous setting.
+
+    ``"fp32"`` (default): exact fp32 products.  ``"bf16"``: operands of every dense product (forward,
+    data gradient, weight gradient) rounded to bfloat16, fp32 accumulation.  ``"bf16-fwd-dgrad"`` /
+    ``"bf16-fwd"``: only those products take bf16 operands, the others stay exact."""
+    if precision not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+    prev = _lib.value("hivt_set_matmul_bf16", _PRECISIONS[precision])
+    for name, mask in _PRECISIONS.items():
+        if mask == prev:
+            return name
+    return "bf16"
 
 
 class _FusedLinear(torch.autograd.Function):

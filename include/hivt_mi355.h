@@ -466,11 +466,15 @@ int hivt_weighted_mean_bwd(const float* g_out, const float* w, const float* coun
                            hivt_stream_t stream);
 
 /* Operand precision of hivt_linear_fwd / hivt_linear_bwd_data / hivt_linear_wgrad (and of everything built
- * on them): 0 (default) = fp32 operands on the fp32 matrix instructions, exact; non-zero = operands rounded
- * to bfloat16 (nearest even) on their way into LDS and multiplied by v_mfma_f32_32x32x8_bf16 with fp32
- * accumulation -- inputs, outputs, epilogues, bias sums and reductions stay fp32.  Process-wide; returns
- * the previous setting.  No counterpart in the reference, which trains in fp32 throughout. */
-int hivt_set_matmul_bf16(int enable);
+ * on them), one bit per product: a product whose bit is clear (default: all clear) takes fp32 operands on the
+ * fp32 matrix instructions, exact; with its bit set the operands are rounded to bfloat16 (nearest even) on
+ * their way into LDS and multiplied by the bf16 matrix instructions with fp32 accumulation -- inputs,
+ * outputs, epilogues, bias sums and reductions stay fp32.  Process-wide; returns the previous mask.  No
+ * counterpart in the reference, which trains in fp32 throughout. */
+#define HIVT_BF16_FWD 1   /* y = x w^T */
+#define HIVT_BF16_DGRAD 2 /* dx = dy w */
+#define HIVT_BF16_WGRAD 4 /* dw = dy^T x */
+int hivt_set_matmul_bf16(int mask);
 
 #ifdef __cplusplus
 }
