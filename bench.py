@@ -264,8 +264,10 @@ def main():
                        "guards": "host" if args.host_guards else "device",
                        "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,
                        "precision": "fp32 throughout" if args.matmul == "fp32" else
-                       "dense products on bf16 operands with fp32 accumulation; attention, norms, losses, "
-                       "optimizer state fp32"},
+                       "dense products on the bf16 matrix instructions with fp32 accumulation: forward products on "
+                       "split (hi + lo) bf16 operands, gradient products on bf16 operands; attention, norms, "
+                       "losses, optimizer state and all tensors in memory fp32; every parameter gradient within "
+                       "2e-2 of the float64 oracle (tests/test_gpu_config3.py)"},
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},
         }
@@ -273,7 +275,7 @@ def main():
             result["matmul_variant"] = {"matmul": other[0], "ms_per_step": other[1] / args.steps * 1e3,
                                         "value": world * args.scenes * args.steps / other[1], "unit": "scenes/sec",
                                         "note": "same step and schedule, dense products on "
-                                                + ("bf16 operands (fp32 accumulation, results within 2e-2)"
+                                                + ("the bf16 matrix instructions (results within 2e-2)"
                                                    if other[0] == "bf16" else "fp32 operands")}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.embed_dim, args.cpu_scenes, args.cpu_steps)

@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
@@ -55,14 +56,27 @@ struct Operand {
   int32_t vec_ok; // 16-byte vector loads are legal (alignment + multiples of 4)
 };
 
-// BF16: the LDS image holds bfloat16 [row][k] (k contiguous, row pitch kBK + 4 halves = 72 bytes: the
-// 8-byte operand reads of 32 consecutive rows then fall on 32 distinct bank pairs); values are rounded
-// to nearest-even on their way from the fp32 registers to LDS, sums that leave the stage stay fp32.
-template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, bool BF16 = false>
+// Operand precision of a product.
+//   PREC_F32    fp32 operands on v_mfma_f32_32x32x2_f32 (exact)
+//   PREC_BF16   operands rounded to bfloat16 (nearest even) on v_mfma_f32_32x32x16_bf16
+//   PREC_SPLIT  every operand value x enters as the pair (hi, lo) = (bf16(x), bf16(x - hi)) and a product is
+//               the three bf16 products hi*hi + hi*lo + lo*hi: 16 significant bits per operand, results
+//               within about 1e-5 of the fp32 ones at three matrix instructions instead of one
+enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
+
+// bf16 modes: the LDS image holds bfloat16 [row][k] (k contiguous, row pitch kBK + 8 halves = 80 bytes: the
+// 16-byte operand reads of 16 consecutive rows then start on 16 distinct groups of four banks); values are
+// rounded on their way from the fp32 registers to LDS, sums that leave the stage stay fp32.  PREC_SPLIT
+// keeps a second image of the same shape (the lo parts) PLANE_H halves behind the first.
+template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, int PREC = PREC_F32>
 struct Stage {
+  static constexpr bool BF16 = PREC != PREC_F32;
+  static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
+  static_assert(!SPLIT3 || TRANS, "split operands are built for [row][k] memory images only (the forward product)");
   static constexpr int PITCH = TRANS ? ROWS + 1 : ROWS + 4;
-  static constexpr int PITCH_H = kBK + 4;  // halves per row of the bf16 image
-  static constexpr int FLOATS = BF16 ? ROWS * PITCH_H / 2 : kBK * PITCH;  // LDS floats of one staged step
+  static constexpr int PITCH_H = kBK + 8;  // halves per row of the bf16 image
+  static constexpr int PLANE_H = ROWS * PITCH_H;  // halves of one image
+  static constexpr int FLOATS = BF16 ? (SPLIT3 ? 2 : 1) * PLANE_H / 2 : kBK * PITCH;  // LDS floats of one staged step
   static constexpr int NVEC = ROWS * kBK / 4 / kThreads;  // float4 per thread per step
   // bf16 image of a row-major operand (reduction index strided): a thread owns pieces (2q, 2q + 1) = two
   // consecutive reduction indices of the same four rows, so the rounded values leave as four 32-bit
@@ -174,6 +188,10 @@ struct Stage {
       const int row = idx / (kBK / 4);
       const int red = (idx % (kBK / 4)) * 4;
       *reinterpret_cast<bf16x4*>(image + row * PITCH_H + red) = h;
+      if constexpr (SPLIT3) {
+        const f32x4 rest = f - __builtin_convertvector(h, f32x4);  // exact: hi shares f's leading bits
+        *reinterpret_cast<bf16x4*>(image + PLANE_H + row * PITCH_H + red) = __builtin_convertvector(rest, bf16x4);
+      }
     } else if (TRANS) {
       const int row = idx / (kBK / 4);
       const int red = (idx % (kBK / 4)) * 4;
@@ -219,10 +237,12 @@ struct Tail {
 // DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
 // step s is multiplied (used for small grids, where no other workgroup shares the compute unit to
 // hide the load latency behind; it costs registers, hence occupancy, on large grids).
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false, bool BF16 = false>
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false, int PREC = PREC_F32>
 struct Core {
-  using SA = Stage<BM, TA, VEC, ACC_A, BF16>;
-  using SB = Stage<BN, TB, VEC, false, BF16>;
+  static constexpr bool BF16 = PREC != PREC_F32;
+  static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
+  using SA = Stage<BM, TA, VEC, ACC_A, PREC>;
+  using SB = Stage<BN, TB, VEC, false, PREC>;
   static constexpr int A_FLOATS = SA::FLOATS;
   static constexpr int B_FLOATS = SB::FLOATS;
   static constexpr int C_PITCH = BN + 4;
@@ -257,24 +277,42 @@ struct Core {
     // matrix unit is busy.
     auto multiply = [&](int cur, auto&& between) {
       if constexpr (BF16) {
-        // v_mfma_f32_32x32x8_bf16: lane (row lo, half hi) supplies k = 4*hi .. 4*hi + 3 of its row;
-        // four MFMAs per accumulator cover the 32 k of a step, all twelve operand reads go first
+        // v_mfma_f32_32x32x16_bf16: lane (row lo, half hi) supplies k = 8*hi .. 8*hi + 7 of its row in each
+        // group of 16 k; two groups cover the 32 k of a step, all operand reads (16 bytes each) go first
         const unsigned short* image = reinterpret_cast<const unsigned short*>(lds + cur);
-        const unsigned short* pa = image + (wr * 32 + lo) * SA::PITCH_H + 4 * hi;
-        const unsigned short* pb = image + 2 * A_FLOATS + (wc * 64 + lo) * SB::PITCH_H + 4 * hi;
-        s16x4 av[kBK / 8], b0[kBK / 8], b1[kBK / 8];
+        const unsigned short* pa = image + (wr * 32 + lo) * SA::PITCH_H + 8 * hi;
+        const unsigned short* pb = image + 2 * A_FLOATS + (wc * 64 + lo) * SB::PITCH_H + 8 * hi;
+        constexpr int G = kBK / 16;
+        bf16x8 ah[G], b0h[G], b1h[G], al[G], b0l[G], b1l[G];
 #pragma unroll
-        for (int g = 0; g < kBK / 8; ++g) {
-          av[g] = *reinterpret_cast<const s16x4*>(pa + 8 * g);
-          b0[g] = *reinterpret_cast<const s16x4*>(pb + 8 * g);
-          b1[g] = *reinterpret_cast<const s16x4*>(pb + 32 * SB::PITCH_H + 8 * g);
+        for (int g = 0; g < G; ++g) {
+          ah[g] = *reinterpret_cast<const bf16x8*>(pa + 16 * g);
+          b0h[g] = *reinterpret_cast<const bf16x8*>(pb + 16 * g);
+          b1h[g] = *reinterpret_cast<const bf16x8*>(pb + 32 * SB::PITCH_H + 16 * g);
+          if constexpr (SPLIT3) {
+            al[g] = *reinterpret_cast<const bf16x8*>(pa + SA::PLANE_H + 16 * g);
+            b0l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 16 * g);
+            b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 32 * SB::PITCH_H + 16 * g);
+          }
         }
 #pragma unroll
-        for (int g = 0; g < kBK / 8; ++g) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av[g], b0[g], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(av[g], b1[g], acc1, 0, 0, 0);
-          between(4 * g + 1);
-          between(4 * g + 3);
+        for (int g = 0; g < G; ++g) {
+          if constexpr (SPLIT3) {  // the small terms first, the leading one last
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], b0h[g], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], b1h[g], acc1, 0, 0, 0);
+            between(8 * g + 1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b0l[g], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b1l[g], acc1, 0, 0, 0);
+            between(8 * g + 3);
+          }
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b0h[g], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b1h[g], acc1, 0, 0, 0);
+          if constexpr (!SPLIT3) {
+            between(8 * g + 1);
+            between(8 * g + 3);
+          }
+          between(8 * g + 5);
+          between(8 * g + 7);
         }
         return;
       }
@@ -495,9 +533,9 @@ struct FwdArgs {
   int32_t M, N;
 };
 
-template <int BM, int BN, int EPI, bool VEC, bool DEEP = false, bool BF16 = false>
+template <int BM, int BN, int EPI, bool VEC, bool DEEP = false, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
-  using C = Core<BM, BN, true, true, VEC, false, DEEP, BF16>;
+  using C = Core<BM, BN, true, true, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   Operand xa = a.x, wa = a.w;
@@ -608,9 +646,9 @@ struct BwdDataArgs {
   int64_t add_ld;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false, bool BF16 = false>
+template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
-  using C = Core<BM, BN, true, false, VEC, false, DEEP, BF16>;
+  using C = Core<BM, BN, true, false, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
   f32x16 acc0, acc1;
@@ -640,9 +678,9 @@ struct WgradArgs {
   int32_t N, K, M, chunk_rows;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false, bool BF16 = false>
+template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
-  using C = Core<BM, BN, false, false, VEC, true, DEEP, BF16>;
+  using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   __shared__ float bsum[kThreads / (BM / 4)][BM];
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
@@ -1028,7 +1066,8 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
 using namespace hivt;
 
 extern "C" int hivt_set_matmul_bf16(int mask) {
-  return g_matmul_bf16.exchange(mask & (HIVT_BF16_FWD | HIVT_BF16_DGRAD | HIVT_BF16_WGRAD), std::memory_order_relaxed);
+  return g_matmul_bf16.exchange(mask & (HIVT_BF16_FWD | HIVT_BF16_DGRAD | HIVT_BF16_WGRAD | HIVT_BF16_FWD_SPLIT),
+                                std::memory_order_relaxed);
 }
 
 #ifdef HIVT_PROBE
@@ -1077,11 +1116,15 @@ static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
-  const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_FWD) != 0;
+  const int mask = g_matmul_bf16.load(std::memory_order_relaxed);
+  const bool split = (mask & HIVT_BF16_FWD_SPLIT) != 0;
+  const bool bf16 = !split && (mask & HIVT_BF16_FWD) != 0;
   // grids that leave compute units with a single workgroup get the deep-prefetch variant
 #define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
-  if (vec && bf16) /* bf16 forward: the deep-prefetch variant wins at every grid size (13-20 % on large ones) */ \
-    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, true>), grid, dim3(kThreads), 0, s, a);  \
+  if (vec && split)                                                                                          \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, PREC_SPLIT>), grid, dim3(kThreads), 0, s, a); \
+  else if (vec && bf16) /* bf16 forward: the deep-prefetch variant wins at every grid size (13-20 % on large ones) */ \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);  \
   else if (vec && grid.x * grid.y <= kSmallGrid)                                                             \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true>), grid, dim3(kThreads), 0, s, a);        \
   else if (vec)                                                                                              \
@@ -1144,9 +1187,9 @@ static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, 
   if (K <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), 1);
     if (vec && bf16 && grid.x <= kSmallGrid)
-      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true, true>), grid, dim3(kThreads), 0, s, a);
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
     else if (vec && bf16)
-      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, false, true>), grid, dim3(kThreads), 0, s, a);
+      hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, false, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
     else if (vec && grid.x <= kSmallGrid)
       hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true>), grid, dim3(kThreads), 0, s, a);
     else if (vec)
@@ -1156,9 +1199,9 @@ static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, 
   } else {
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 127) / 128));
     if (vec && bf16 && grid.x * grid.y <= kSmallGrid)
-      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true, true>), grid, dim3(kThreads), 0, s, a);
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
     else if (vec && bf16)
-      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, false, true>), grid, dim3(kThreads), 0, s, a);
+      hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, false, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
     else if (vec && grid.x * grid.y <= kSmallGrid)
       hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
     else if (vec)
@@ -1234,9 +1277,9 @@ static int linear_wgrad_impl(const float* dy, int64_t dy_ld, const float* x, int
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
   const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_WGRAD) != 0;
   if (a.dy.vec_ok && a.x.vec_ok && bf16 && grid.x * grid.y * grid.z <= kSmallGrid)
-    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, true>), grid, dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok && bf16)
-    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, false, true>), grid, dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, false, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok && grid.x * grid.y * grid.z <= kSmallGrid)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok)

@@ -95,13 +95,13 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, flo
 // WPN  = waves that share one target row (1, or 4 for long rows, merged through LDS)
 // SPLIT = short-row mode: every lane slot (LPR lanes) of a wave owns its OWN target row, so a wave
 //         serves 64/LPR rows at once and no slot merge is needed (requires WPN == 1)
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
 __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) {
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
   constexpr int RPW = SPLIT ? EPI : 1;
-  constexpr int kUnroll = SPLIT ? kUnrollShort : (WPN > 1 ? kUnrollWide : kUnrollLong);
+  constexpr int kUnroll = UNROLL;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
 
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
 __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? EPI : 1;
-  constexpr int kUnroll = SPLIT ? kUnrollShort : (WPN > 1 ? kUnrollWide : kUnrollLong);
+  constexpr int kUnroll = UNROLL;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
 
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void zero_tail_kernel(const int32_t* __restric
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT>
+template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
 int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? kWave / (D / 4) : 1;
@@ -339,69 +339,109 @@ int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
     k.ev_start = nullptr;
     k.ev_stop = nullptr;
     if (backward)
-      hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream,
+      hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream,
                             a.ev_start, a.ev_stop, 0, k);
     else
-      hipExtLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream,
+      hipExtLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream,
                             a.ev_start, a.ev_stop, 0, k);
     return 0;
   }
   if (backward)
-    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT>), dim3(grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
   return 0;
 }
 
-// mode 0: short rows (one row per lane slot), 1: one wave per row, 2: four waves per row
+template <int D, int LPH, int WPN, bool SPLIT, int UNROLL>
+int launch_g(bool backward, bool global, const SegAttnArgs& a, hipStream_t stream) {
+  return global ? launch_one<D, LPH, WPN, true, SPLIT, UNROLL>(backward, a, stream)
+                : launch_one<D, LPH, WPN, false, SPLIT, UNROLL>(backward, a, stream);
+}
+
+// Launch shapes.  `waves`: 0 = one target row per lane slot (short rows), 1 / 2 / 4 = waves of a block that
+// share one row; `unroll` = edges in flight per lane slot.
+struct Shape {
+  int waves;
+  int unroll;
+};
+
+// By average row length (measured on 1.3-, 18- and 54-edge rows at D = 128): rows shorter than two unrolled
+// passes of a lane slot go one per slot; long rows are split over the 4 waves of a block with 8 edges in
+// flight per slot; rows in between take one wave and a short batch forward, but four waves backward, where
+// every edge also costs two stores and the wider split keeps more of them in flight.
+Shape default_shape(int64_t E, int32_t N, bool backward) {
+  const int64_t avg = N > 0 ? E / N : 0;
+  if (avg >= 48) return {4, kUnrollWide};
+  if (avg < 8) return {0, kUnrollShort};
+  return backward ? Shape{4, 4} : Shape{1, 2};
+}
+
 template <int D, int LPH>
-int launch_dl(bool backward, int mode, bool global, const SegAttnArgs& a, hipStream_t stream) {
+int launch_dl(bool backward, Shape sh, bool global, const SegAttnArgs& a, hipStream_t stream) {
   if constexpr (LPH <= D / 4) {
-    if (mode == 2) {
-      return global ? launch_one<D, LPH, 4, true, false>(backward, a, stream)
-                    : launch_one<D, LPH, 4, false, false>(backward, a, stream);
+    if (sh.waves == 0 && D >= 256) sh = {1, kUnrollLong};
+#define HIVT_SHAPE(W_, SPLIT_, U_) \
+  if (sh.waves == (SPLIT_ ? 0 : W_) && sh.unroll == U_) return launch_g<D, LPH, W_, SPLIT_, U_>(backward, global, a, stream);
+    // the three default shapes exist for every row width
+    HIVT_SHAPE(4, false, kUnrollWide)
+    HIVT_SHAPE(1, true, kUnrollShort)
+    HIVT_SHAPE(1, false, kUnrollLong)
+    HIVT_SHAPE(4, false, 4)
+    HIVT_SHAPE(1, false, 2)
+    if constexpr (D == 128) {  // further shapes of the benchmarked width, reachable through the shape hint
+      HIVT_SHAPE(4, false, 2)
+      HIVT_SHAPE(2, false, 2)
+      HIVT_SHAPE(2, false, 4)
+      HIVT_SHAPE(2, false, 8)
+      HIVT_SHAPE(1, false, 8)
+      HIVT_SHAPE(1, true, 4)
+      HIVT_SHAPE(1, true, 8)
     }
-    if (mode == 0 && D < 256) {
-      return global ? launch_one<D, LPH, 1, true, true>(backward, a, stream)
-                    : launch_one<D, LPH, 1, false, true>(backward, a, stream);
-    }
-    return global ? launch_one<D, LPH, 1, true, false>(backward, a, stream)
-                  : launch_one<D, LPH, 1, false, false>(backward, a, stream);
+#undef HIVT_SHAPE
+    return -1;
   } else {
     return -1;
   }
 }
 
 template <int D>
-int launch_d(int lph, bool backward, int mode, bool global, const SegAttnArgs& a, hipStream_t stream) {
+int launch_d(int lph, bool backward, Shape sh, bool global, const SegAttnArgs& a, hipStream_t stream) {
   switch (lph) {
-    case 1: return launch_dl<D, 1>(backward, mode, global, a, stream);
-    case 2: return launch_dl<D, 2>(backward, mode, global, a, stream);
-    case 4: return launch_dl<D, 4>(backward, mode, global, a, stream);
-    case 8: return launch_dl<D, 8>(backward, mode, global, a, stream);
+    case 1: return launch_dl<D, 1>(backward, sh, global, a, stream);
+    case 2: return launch_dl<D, 2>(backward, sh, global, a, stream);
+    case 4: return launch_dl<D, 4>(backward, sh, global, a, stream);
+    case 8: return launch_dl<D, 8>(backward, sh, global, a, stream);
     default: return -1;
   }
 }
 
-int dispatch(int D, int H, bool backward, int64_t E, bool global, const SegAttnArgs& a, hipStream_t stream) {
+// hint: bits 8-11 of the dtype argument = waves code (0 auto, 1 = one row per lane slot, 2 / 3 / 4 = 1 / 2 / 4
+// waves per row), bits 12-15 = edges in flight per lane slot (0 auto)
+int dispatch(int D, int H, bool backward, int64_t E, bool global, int hint, const SegAttnArgs& a, hipStream_t stream) {
   const int lph = D / (4 * H);
-  // by average row length: rows shorter than two unrolled passes of a lane slot go one per slot,
-  // long rows are split over the 4 waves of a block
-  const int64_t avg = a.N > 0 ? E / a.N : 0;
-  const int mode = avg >= 48 ? 2 : (avg < 8 ? 0 : 1);
+  Shape sh = default_shape(E, a.N, backward);
+  const int wcode = (hint >> 8) & 15, ucode = (hint >> 12) & 15;
+  if (wcode != 0) {
+    static const int kWaves[5] = {0, 0, 1, 2, 4};
+    if (wcode > 4) return -1;
+    sh.waves = kWaves[wcode];
+    sh.unroll = sh.waves == 0 ? kUnrollShort : (sh.waves == 4 ? kUnrollWide : kUnrollLong);
+  }
+  if (ucode != 0) sh.unroll = ucode;
   switch (D) {
-    case 16: return launch_d<16>(lph, backward, mode, global, a, stream);
-    case 32: return launch_d<32>(lph, backward, mode, global, a, stream);
-    case 64: return launch_d<64>(lph, backward, mode, global, a, stream);
-    case 128: return launch_d<128>(lph, backward, mode, global, a, stream);
-    case 256: return launch_d<256>(lph, backward, mode, global, a, stream);
+    case 16: return launch_d<16>(lph, backward, sh, global, a, stream);
+    case 32: return launch_d<32>(lph, backward, sh, global, a, stream);
+    case 64: return launch_d<64>(lph, backward, sh, global, a, stream);
+    case 128: return launch_d<128>(lph, backward, sh, global, a, stream);
+    case 256: return launch_d<256>(lph, backward, sh, global, a, stream);
     default: return -1;
   }
 }
 
 int check_shape(const char* what, int32_t N, int64_t E, int32_t D, int32_t H, int64_t kv_stride, int dtype,
                 float dropout_p) {
-  HIVT_REQUIRE(dtype == HIVT_F32, HIVT_ERR_UNSUPPORTED, "%s: only HIVT_F32 is built", what);
+  HIVT_REQUIRE((dtype & 255) == HIVT_F32, HIVT_ERR_UNSUPPORTED, "%s: only HIVT_F32 is built", what);
   HIVT_REQUIRE(N >= 0 && E >= 0 && E < (int64_t)1 << 31, HIVT_ERR_ARG, "%s: bad sizes N=%d E=%lld", what, N,
                (long long)E);
   HIVT_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128 || D == 256, HIVT_ERR_ARG,
@@ -445,8 +485,8 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = out; a.m = m_out; a.den = den_out;
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
-  HIVT_REQUIRE(dispatch(D, H, false, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
-               "%s: no kernel for D=%d H=%d", what, D, H);
+  HIVT_REQUIRE(dispatch(D, H, false, E, global, dtype, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
+               "%s: no kernel for D=%d H=%d (launch-shape hint 0x%x)", what, D, H, dtype >> 8);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
@@ -497,8 +537,8 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
   a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);
   a.d_out = d_out; a.dq = dq; a.dk = dk; a.dv = dv; a.dkv_stride = dkv_stride;
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
-  HIVT_REQUIRE(dispatch(D, H, true, E, global, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
-               "%s: no kernel for D=%d H=%d", what, D, H);
+  HIVT_REQUIRE(dispatch(D, H, true, E, global, dtype, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
+               "%s: no kernel for D=%d H=%d (launch-shape hint 0x%x)", what, D, H, dtype >> 8);
   HIVT_CHECK_LAUNCH(what);
   if (zero_tail && E > 0) {
     hipLaunchKernelGGL(zero_tail_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, rowptr, N, E, D, dk, dv,

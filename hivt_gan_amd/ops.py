@@ -500,7 +500,7 @@ def _pass_through_grad(dy: torch.Tensor, shape, to_leaf: bool) -> torch.Tensor:
     return g.clone() if to_leaf else g
 
 
-_PRECISIONS = {"fp32": 0, "bf16": 7, "bf16-fwd": 1, "bf16-fwd-dgrad": 3}
+_PRECISIONS = {"fp32": 0, "bf16": 14, "bf16-plain": 7, "bf16-fwd": 1, "bf16-bwd": 6, "bf16-split-fwd": 8}
 
 
 def set_matmul_precision(precision: str) -> str:

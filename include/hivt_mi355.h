@@ -474,6 +474,12 @@ int hivt_weighted_mean_bwd(const float* g_out, const float* w, const float* coun
 #define HIVT_BF16_FWD 1   /* y = x w^T */
 #define HIVT_BF16_DGRAD 2 /* dx = dy w */
 #define HIVT_BF16_WGRAD 4 /* dw = dy^T x */
+/* Forward product on split operands: every value enters as hi = bf16(x), lo = bf16(x - hi) and the product is
+ * hi*hi + hi*lo + lo*hi on the bf16 matrix instructions (16 significant bits per operand, results within about
+ * 1e-5 of the fp32 ones).  Overrides HIVT_BF16_FWD.  Rounding the forward operands to 8 bits moves the
+ * parameter gradients of the network by about 1e-1 (they depend on the saved activations); rounding only the
+ * gradient products moves them by under 1e-2. */
+#define HIVT_BF16_FWD_SPLIT 8
 int hivt_set_matmul_bf16(int mask);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ TOL = 2e-2
 
 @pytest.fixture()
 def bf16_mode():
-    prev = ops.set_matmul_precision("bf16")
+    prev = ops.set_matmul_precision("bf16-plain")
     try:
         yield
     finally:
@@ -51,6 +51,30 @@ def test_bf16_products_forward_backward(bf16_mode, M, K, N, ln, relu):
     for g, t, name in zip(got, (xd, wd, bd), ("dx", "dw", "db")):
         assert rel(g, t.grad) < TOL, name
     assert rel(y, ref) > 1e-5, "the bf16 path did not run (result is fp32-exact)"
+
+
+@pytest.mark.parametrize("M,K,N,ln,relu", [(3000, 128, 128, True, True), (70_001, 128, 256, False, True),
+                                           (2623, 512, 128, False, False), (515, 64, 64, True, False),
+                                           (130, 128, 60, False, False)])
+def test_split_bf16_forward_product_is_within_1e4_of_float64(M, K, N, ln, relu):
+    """The forward product of the "bf16" mode takes every operand as a (hi, lo) pair of bfloat16 values
+    and sums three bf16 products: 16 significant bits per operand."""
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device=DEV)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    norm = torch.nn.LayerNorm(N).to(DEV) if ln else None
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        with torch.no_grad():
+            y = ops.fused_linear(x, lin.weight, lin.bias, layer_norm=norm, relu=relu)
+    finally:
+        ops.set_matmul_precision(prev)
+    ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    if ln:
+        ref = torch.nn.functional.layer_norm(ref, (N,), norm.weight.double(), norm.bias.double(), norm.eps)
+    if relu:
+        ref = ref.clamp(min=0)
+    assert 2e-7 < rel(y, ref) < 1e-4, rel(y, ref)
 
 
 def test_bf16_mode_full_step_close_to_fp32_and_switch_restores_exact_mode():
@@ -105,7 +129,7 @@ def test_bf16_mode_full_step_close_to_fp32_and_switch_restores_exact_mode():
         return torch.cat([p.grad.flatten() for p in m.generator_parameters() if p.grad is not None]).double()
 
     s32 = smooth_gradient()
-    prev = ops.set_matmul_precision("bf16")
+    prev = ops.set_matmul_precision("bf16-plain")
     try:
         s16 = smooth_gradient()
     finally:

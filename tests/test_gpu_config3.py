@@ -46,8 +46,8 @@ def _loss_with_given_best(y_hat, pi, y, padding_mask, best, t_hist=20):
     return reg, cls
 
 
-@pytest.fixture(scope="module")
-def report():
+def precision_report(modes=("fp32", "bf16", "bf16-plain", "bf16-bwd", "bf16-split-fwd"), save=True):
+    """Per-mode relative errors of outputs, losses and every parameter gradient against the float64 oracle."""
     torch.manual_seed(2022)
     model = hv.HiVT(**CFG128, lr=5e-4, weight_decay=1e-4, T_max=64).to(DEV)
     model.train()
@@ -72,7 +72,7 @@ def report():
                smooth=dict(zip(names, smooth_ref)), loss=dict(zip(names, loss_ref)))
 
     out = {}
-    for mode in ("fp32", "bf16", "bf16-fwd-dgrad", "bf16-fwd"):
+    for mode in modes:
         prev = ops.set_matmul_precision(mode)
         try:
             res = {}
@@ -108,6 +108,8 @@ def report():
             ops.set_matmul_precision(prev)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
+        if not save:
+            raise OSError
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, "config3_precision_report.json"), "w") as f:
             json.dump(out, f, indent=1)
@@ -121,14 +123,43 @@ def report():
     return out
 
 
+@pytest.fixture(scope="module")
+def report():
+    return precision_report()
+
+
+def _worst(per):
+    return max(per.items(), key=lambda kv: kv[1])
+
+
 def test_fp32_mode_hivt128_within_1e5_of_the_float64_oracle(report):
     r = report["fp32"]
     assert r["y_hat"] < 1e-5 and r["pi"] < 1e-5 and r["reg_loss"] < 1e-5 and r["cls_loss"] < 1e-5, r
     assert r["best_mode_agreement"] == 1.0
-    assert r["smooth_grad_whole"] < 1e-5 and r["loss_grad_whole"] < 1e-5
+    for kind in ("smooth", "loss"):
+        assert r[f"{kind}_grad_whole"] < 1e-5
+        name, err = _worst(r[f"{kind}_grad_per_tensor"])
+        assert err < 1e-5, f"{kind} gradient of {name}: {err:.2e}"
 
 
-def test_bf16_mode_hivt128_outputs_and_losses_within_2e2(report):
+def test_bf16_mode_hivt128_within_2e2_of_the_float64_oracle(report):
+    """The named workload's precision: forward products on split bf16 operands, gradient products on bf16
+    operands.  Outputs, losses and EVERY parameter gradient stay within 2e-2 (relative L2 per tensor)."""
     r = report["bf16"]
-    assert 1e-6 < r["y_hat"] < 2e-2 and r["pi"] < 2e-2, (r["y_hat"], r["pi"])
-    assert r["reg_loss"] < 2e-2 and r["cls_loss"] < 2e-2
+    assert 1e-6 < r["y_hat"] < 1e-3 and r["pi"] < 1e-3, (r["y_hat"], r["pi"])
+    assert r["reg_loss"] < 1e-4 and r["cls_loss"] < 1e-4
+    assert r["best_mode_agreement"] == 1.0
+    for kind in ("smooth", "loss"):
+        assert r[f"{kind}_grad_whole"] < 1e-2, (kind, r[f"{kind}_grad_whole"])
+        name, err = _worst(r[f"{kind}_grad_per_tensor"])
+        assert err < 2e-2, f"{kind} gradient of {name}: {err:.2e}"
+
+
+def test_plain_bf16_forward_operands_do_not_hold_2e2_on_the_gradients(report):
+    """Why the forward product is split: with its operands rounded to 8 significant bits the outputs stay
+    inside 2e-2 but the parameter gradients, which depend on the saved activations, move by about 1e-1.
+    (Rounding only the gradient products keeps every tensor within about 1e-2.)"""
+    plain, bwd_only = report["bf16-plain"], report["bf16-bwd"]
+    assert plain["y_hat"] < 2e-2 and plain["pi"] < 2e-2
+    assert plain["smooth_grad_whole"] > 2e-2
+    assert _worst(bwd_only["smooth_grad_per_tensor"])[1] < 2e-2 and _worst(bwd_only["loss_grad_per_tensor"])[1] < 2e-2

@@ -23,7 +23,8 @@ def timeit(fn, iters=20, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for (M, K, N) in [(136_000, 128, 128), (136_000, 128, 256), (52_000, 128, 512), (52_000, 512, 128), (2_623, 256, 256)]:
+for (M, K, N) in [(136_000, 128, 128), (136_000, 128, 256), (52_000, 128, 512), (52_000, 512, 128), (2_623, 256, 256),
+                  (2_623, 128, 128), (2_623, 128, 768)]:
     x = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev)
     b = torch.randn(N, device=dev)
@@ -35,7 +36,8 @@ for (M, K, N) in [(136_000, 128, 128), (136_000, 128, 256), (52_000, 128, 512), 
     ws = torch.empty(_lib.query("hivt_linear_wgrad_workspace_bytes", M, N, K), dtype=torch.uint8, device=dev)
     s = ops._stream(x)
     row = f"M={M:7d} K={K:4d} N={N:4d} |"
-    for mode in ("fp32", "bf16"):
+    ref = (x.double() @ w.double().t() + b.double())
+    for mode in ("fp32", "bf16-plain", "bf16"):
         ops.set_matmul_precision(mode)
         tf = timeit(lambda: _lib.call("hivt_linear_fwd", x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), None, 0, None, 0,
                                       None, None, 0.0, 0, 1.0, 0.0, 0, None, None, 0, M, N, K, y.data_ptr(), N, None, 0,
@@ -44,6 +46,7 @@ for (M, K, N) in [(136_000, 128, 128), (136_000, 128, 256), (52_000, 128, 512), 
                                       None, 0, dx.data_ptr(), K, s))
         tw = timeit(lambda: _lib.call("hivt_linear_wgrad", dy.data_ptr(), N, x.data_ptr(), K, M, N, K, dw.data_ptr(),
                                       db.data_ptr(), ws.data_ptr(), ws.numel(), s))
-        row += f" {mode}: fwd {tf:6.1f} dX {tb:6.1f} dW {tw:6.1f} us |"
+        err = float((y.double() - ref).norm() / ref.norm())
+        row += f" {mode}: fwd {tf:6.1f} (err {err:.1e}) dX {tb:6.1f} dW {tw:6.1f} us |"
     ops.set_matmul_precision("fp32")
     print(row)
