@@ -81,6 +81,7 @@ SIGNATURES = {
     "hivt_set_matmul_bf16": (c_int, [c_int]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hivt_step_guards": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P]),
     "hivt_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, _P, c_float, c_float, c_float, c_float, c_float, _P]),
 }
 

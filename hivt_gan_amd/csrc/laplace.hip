@@ -247,3 +247,49 @@ extern "C" int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
+
+
+// ---- guards of the training step ------------------------------------------------------------------
+namespace hivt {
+namespace {
+
+__global__ void guard_init_kernel(const uint8_t* __restrict__ extra, int32_t* __restrict__ flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) flag[0] = (extra != nullptr && extra[0] != 0) ? 1 : 0;
+}
+
+// FINITE = false: looks for NaN; true: for NaN or infinity.  A block that finds one ORs 1 into the flag
+// (an idempotent integer atomic: the result does not depend on arrival order).
+template <bool FINITE>
+__global__ __launch_bounds__(256) void guard_scan_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag) {
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    bad |= FINITE ? !(fabsf(v) <= 3.402823466e38f) : (v != v);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+}  // namespace hivt
+
+extern "C" int hivt_step_guards(const float* nan_check, int64_t n_nan, const float* finite_check, int64_t n_finite,
+                                const uint8_t* extra, int32_t* flag, hivt_stream_t stream_) {
+  const char* what = "hivt_step_guards";
+  hipStream_t stream = (hipStream_t)stream_;
+  HIVT_REQUIRE(flag != nullptr && n_nan >= 0 && n_finite >= 0, HIVT_ERR_ARG, "%s: bad arguments", what);
+  HIVT_REQUIRE((n_nan == 0 || nan_check) && (n_finite == 0 || finite_check), HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(guard_init_kernel, dim3(1), dim3(64), 0, stream, extra, flag);
+  HIVT_CHECK_LAUNCH(what);
+  auto blocks = [](int64_t n) { int64_t b = (n + 1023) / 1024; return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); };
+  if (n_nan > 0) {
+    hipLaunchKernelGGL((guard_scan_kernel<false>), dim3(blocks(n_nan)), dim3(256), 0, stream, nan_check, n_nan, flag);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  if (n_finite > 0) {
+    hipLaunchKernelGGL((guard_scan_kernel<true>), dim3(blocks(n_finite)), dim3(256), 0, stream, finite_check, n_finite,
+                       flag);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  return HIVT_OK;
+}

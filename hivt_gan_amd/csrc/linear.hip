@@ -958,18 +958,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // the gradient of a small embedding table whose rows were added per row of a big tensor.  A wave
 // strides over rows with one register accumulator per (code, owned column); selection by comparison
 // instead of indexed accumulation keeps everything in registers and the sums in a fixed order.
-constexpr int kMaxCodes = 16;
+constexpr int kMaxCodes = 32;
 
-template <int NPL>
+template <int NPL, int CODES>  // CODES: compile-time bound on R (16 or 32): one register accumulator per code
 __global__ __launch_bounds__(256) void rowsum_by_code_kernel(const float* __restrict__ x, int64_t x_ld,
                                                              const int32_t* __restrict__ index, int64_t M, int N,
                                                              int R, float* __restrict__ partial /*[grid][R][N]*/) {
-  __shared__ float red[4][kMaxCodes][64 * NPL];
+  __shared__ float red[CODES][64 * NPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * NPL;
-  float acc[kMaxCodes][NPL];
+  float acc[CODES][NPL];
 #pragma unroll
-  for (int r = 0; r < kMaxCodes; ++r)
+  for (int r = 0; r < CODES; ++r)
 #pragma unroll
     for (int j = 0; j < NPL; ++j) acc[r][j] = 0.0f;
   const int64_t stride = (int64_t)gridDim.x * 4;
@@ -988,18 +988,28 @@ __global__ __launch_bounds__(256) void rowsum_by_code_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < kMaxCodes; ++r)
+      for (int r = 0; r < CODES; ++r)
 #pragma unroll
         for (int j = 0; j < NPL; ++j) acc[r][j] += (code[u] == r) ? v[u][j] : 0.0f;
   }
+  // the four waves add their sums one after the other: ((w0 + w1) + w2) + w3, a fixed order
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int r = 0; r < kMaxCodes; ++r)
+      for (int r = 0; r < CODES; ++r)
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) red[wave][r][c0 + j] = acc[r][j];
-  __syncthreads();
+        for (int j = 0; j < NPL; ++j) {
+          if (w == 0)
+            red[r][c0 + j] = acc[r][j];
+          else
+            red[r][c0 + j] += acc[r][j];
+        }
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < R * N; i += 256) {
     const int r = i / N, c = i % N;
-    partial[((int64_t)blockIdx.x * R + r) * N + c] = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+    partial[((int64_t)blockIdx.x * R + r) * N + c] = red[r][c];
   }
 }
 
@@ -1403,11 +1413,17 @@ extern "C" int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* 
   int64_t blocks = (M + 7) / 8;
   if (blocks > 512) blocks = 512;
   float* partial = reinterpret_cast<float*>(workspace);
-  if (N <= 64)
-    hipLaunchKernelGGL((rowsum_by_code_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+  if (N <= 64 && R <= 16)
+    hipLaunchKernelGGL((rowsum_by_code_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+                       partial);
+  else if (N <= 64)
+    hipLaunchKernelGGL((rowsum_by_code_kernel<1, 32>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+                       partial);
+  else if (R <= 16)
+    hipLaunchKernelGGL((rowsum_by_code_kernel<2, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
                        partial);
   else
-    hipLaunchKernelGGL((rowsum_by_code_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
+    hipLaunchKernelGGL((rowsum_by_code_kernel<2, 32>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
                        partial);
   HIVT_CHECK_LAUNCH(what);
   reduce_partials(partial, (int)blocks, R * N, out, s);

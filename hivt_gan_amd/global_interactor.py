@@ -119,5 +119,9 @@ class GlobalInteractor(nn.Module):
         for layer in self.global_interactor_layers:
             x = layer(x, None, rel_embed, edges=edges)
         x = ops.layer_norm(x, self.norm)
-        x = self.multihead_proj(x).view(-1, self.num_modes, self.embed_dim)
+        if x.is_cuda and x.dtype == torch.float32:
+            x = ops.fused_linear(x, self.multihead_proj.weight, self.multihead_proj.bias)
+        else:
+            x = self.multihead_proj(x)
+        x = x.view(-1, self.num_modes, self.embed_dim)
         return x.transpose(0, 1)

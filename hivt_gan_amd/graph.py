@@ -1,0 +1,150 @@
+"""The G + D + R1 step recorded once into a HIP graph and replayed.
+
+An eagerly launched step is about a thousand kernel launches of a few microseconds each, so the
+launch thread, not the GPU, bounds it on all but the fastest hosts.  Everything a recorded step needs
+is in place in the read-back-free mode of ``GanTrainer`` (``edge_capacity``): tensor shapes are fixed
+(``pad_batch``), live edge counts, guards and the overflow flag stay in device memory, the library
+launches plain kernels only (no runtime memset / memcpy, no allocation), the optimizers read their step
+counter and the skip flag from device memory, and every dropout site adds a device-side seed to its
+per-call constant, which the recorded step advances by itself.
+
+What a recorded step fixes until it is recorded again: the learning rate (``GanTrainer.end_epoch``
+invalidates the recording), the critic-stream schedule, the batch shapes (``BatchSpec``).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import losses, ops
+from .data import BatchSpec, TemporalData, pad_batch
+
+# per-replay advance of the device-side dropout seed: an odd constant unrelated to the multiplier the
+# kernels use per element, so that consecutive steps do not see shifted copies of one mask
+_SEED_STRIDE = 0x51342543DE82EF95
+
+# tensors of a padded batch that a step reads
+_INPUT_KEYS = ("x", "positions", "y", "padding_mask", "bos_mask", "rotate_angles", "lane_vectors", "is_intersections",
+               "turn_directions", "traffic_controls", "edge_index", "lane_actor_index", "lane_actor_vectors")
+
+
+_HIP_NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+                   7: "event_record"}
+
+
+def node_census(graph: "torch.cuda.CUDAGraph") -> Dict[str, int]:
+    """Nodes of a recorded graph (constructed with ``keep_graph=True``) by kind, read through
+    hipGraphGetNodes / hipGraphNodeGetType."""
+    import collections
+    import ctypes
+    handle = graph.raw_cuda_graph()
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_size_t(0)
+    rc = hip.hipGraphGetNodes(ctypes.c_void_p(handle), None, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"hipGraphGetNodes failed with code {rc}")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    hip.hipGraphGetNodes(ctypes.c_void_p(handle), nodes, ctypes.byref(n))
+    kinds = collections.Counter()
+    for node in nodes[:n.value]:
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t))
+        kinds[_HIP_NODE_KINDS.get(t.value, f"type{t.value}")] += 1
+    return dict(kinds)
+
+
+class GraphedStep:
+    """``trainer.step`` on fixed-shape batches as one graph launch.
+
+    ``example`` is a batch already padded to ``spec`` and resident on the GPU; its tensors become the
+    static inputs of the recording.  ``run(batch)`` copies another padded batch into them (thirteen
+    device-to-device copies) and replays; ``run()`` replays on whatever the static inputs hold."""
+
+    def __init__(self, trainer, spec: BatchSpec, example: TemporalData, warmup: int = 3,
+                 critic_streams: bool = False) -> None:
+        if trainer.edge_capacity is None:
+            raise RuntimeError("a recorded step needs the read-back-free mode (GanTrainer(edge_capacity=...))")
+        if trainer.distributed:
+            raise RuntimeError("the recorded step covers the single-process step; data-parallel runs launch eagerly")
+        self.trainer = trainer
+        self.spec = spec
+        self.static = TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
+                                      for k in example.keys() if k != "edge_plan"})
+        self._y = self.static["y"]
+        dev = self._y.device
+        self.device = dev
+        self.seed = torch.zeros((), dtype=torch.int64, device=dev)
+        self.critic_streams = bool(critic_streams)
+        self.warmup = int(warmup)
+        self.nodes: Dict[str, int] = {}
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.logs: Dict[str, torch.Tensor] = {}
+        self._stream = torch.cuda.Stream(device=dev)
+        self.replays = 0
+        self.record()
+
+    # ------------------------------------------------------------------------------------------
+    def _one_step(self) -> Dict[str, torch.Tensor]:
+        prev_seed, prev_calls, prev_conc = ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS
+        ops.DEVICE_SEED, ops._seed_calls = self.seed, 0
+        losses.CONCURRENT_CRITICS = self.critic_streams
+        try:
+            self.seed.add_(_SEED_STRIDE)
+            self.static["y"] = self._y       # forward rebinds the entry to the rotated targets
+            self.static["edge_plan"] = None  # edge construction belongs to the step
+            return self.trainer.step(self.static)
+        finally:
+            ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS = prev_seed, prev_calls, prev_conc
+
+    def record(self) -> None:
+        """(Re)records the step: ``warmup`` eager steps on the recording stream (allocator, optimizer
+        state, autograd nodes settle there), then one step under capture."""
+        current = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(current)
+        with torch.cuda.stream(self._stream):
+            for _ in range(self.warmup):
+                self._one_step()
+        current.wait_stream(self._stream)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(self.graph, stream=self._stream):
+            self.logs = self._one_step()
+        # A runtime memset recorded as a graph node takes no effect when the graph is replayed on this stack
+        # (torch 2.10 / ROCm 7.2): a multi-block framework reduction, which clears its semaphores that way,
+        # returns wrong sums from the second replay on.  The step is written to issue none; refuse to replay
+        # a recording that holds one rather than train on wrong numbers.
+        self.nodes = node_census(self.graph)
+        if self.nodes.get("memset", 0):
+            self.graph = None
+            raise RuntimeError(f"the recorded step holds {self.nodes['memset']} runtime memset node(s) {self.nodes}; "
+                               "tools/find_memsets.py names the operators that issue them")
+        self.graph.instantiate()
+        self._lr = [g["lr"] for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None
+                    for g in opt.param_groups]
+
+    def load(self, batch: TemporalData) -> None:
+        """Copies a batch padded to the same ``BatchSpec`` into the static inputs."""
+        for k in _INPUT_KEYS:
+            dst = self._y if k == "y" else self.static[k]
+            src = batch[k]
+            if src.shape != dst.shape:
+                raise ValueError(f"{k}: shape {tuple(src.shape)} does not match the recorded {tuple(dst.shape)}; "
+                                 "pad the batch to the recording's BatchSpec")
+            dst.copy_(src, non_blocking=True)
+
+    def run(self, batch: Optional[TemporalData] = None) -> Dict[str, torch.Tensor]:
+        """One step; returns the recording's loss tensors (overwritten by the next replay)."""
+        lr = [g["lr"] for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None for g in opt.param_groups]
+        if lr != self._lr:  # the learning rate is a launch argument of the recorded update
+            self.record()
+        if batch is not None:
+            self.load(batch)
+        self.graph.replay()
+        self.replays += 1
+        return self.logs
+
+
+def padded_pool(batches, spec: BatchSpec):
+    """Every batch of ``batches`` (GPU) padded to ``spec``."""
+    return [pad_batch(b, spec) for b in batches]

@@ -231,12 +231,18 @@ class HiVT(nn.Module):
     def _training_step_sync_free(self, data, opt_g, opt_d, sync_grads) -> Dict[str, torch.Tensor]:
         y_raw = data["y"]
         y_hat, pi = self(data)
-        bad = torch.zeros((), dtype=torch.bool, device=y_hat.device)
-        if self.check_finite:
-            bad = torch.isnan(y_raw).any() | ~torch.isfinite(y_hat).all()
         plan = data.get("edge_plan")
-        if plan is not None and plan.overflow is not None:
-            bad = bad | plan.overflow  # a fixed-capacity edge list was truncated: discard the batch
+        # a fixed-capacity edge list that was truncated discards the batch like a tripped guard
+        overflow = plan.overflow if (plan is not None and plan.overflow is not None) else None
+        if y_hat.is_cuda:
+            bad = ops.step_guards(y_raw if self.check_finite else None, y_hat if self.check_finite else None, overflow) \
+                if (self.check_finite or overflow is not None) else torch.zeros((), dtype=torch.bool, device=y_hat.device)
+        else:
+            bad = torch.zeros((), dtype=torch.bool, device=y_hat.device)
+            if self.check_finite:
+                bad = torch.isnan(y_raw).any() | ~torch.isfinite(y_hat).all()
+            if overflow is not None:
+                bad = bad | overflow
         logs = self._losses_and_updates(data, y_hat, pi, opt_g, opt_d, sync_grads, bad)
         logs["skipped"] = bad.float()
         return logs

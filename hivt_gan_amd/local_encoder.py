@@ -204,7 +204,10 @@ class AAEncoder(_EdgeAttentionBase):
             if rotate_mat is not None:  # row vector times the agent's 2x2, written out (no batched GEMM)
                 xv = xv[..., 0:1] * rotate_mat[:, 0, :] + xv[..., 1:2] * rotate_mat[:, 1, :]
             center = self.center_embed(xv)
-            center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2), center).reshape(x.shape[0], -1)
+            if ops.step_tokens_supported(center, T):
+                center = ops.masked_step_tokens(center, bos_mask.t(), self.bos_token).reshape(x.shape[0], -1)
+            else:
+                center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2), center).reshape(x.shape[0], -1)
             rot_mod = n
         else:
             xr = x if rotate_mat is None else x[:, 0:1] * rotate_mat[:, 0, :] + x[:, 1:2] * rotate_mat[:, 1, :]
@@ -395,8 +398,12 @@ class TemporalEncoder(nn.Module):
         self.apply(init_weights)
 
     def forward(self, x: torch.Tensor, padding_mask: torch.Tensor) -> torch.Tensor:
-        x = torch.where(padding_mask.t().unsqueeze(-1), self.padding_token, x)
-        x = torch.cat((x, self.cls_token.expand(-1, x.shape[1], -1)), dim=0) + self.pos_embed
+        if ops.step_tokens_supported(x, x.shape[0] + 1):
+            x = ops.masked_step_tokens(x, padding_mask.t(), self.padding_token.squeeze(1))
+            x = ops.append_token_add_steps(x, self.cls_token.view(-1), self.pos_embed.squeeze(1))
+        else:
+            x = torch.where(padding_mask.t().unsqueeze(-1), self.padding_token, x)
+            x = torch.cat((x, self.cls_token.expand(-1, x.shape[1], -1)), dim=0) + self.pos_embed
         return self.transformer_encoder.forward_last(x)
 
     @staticmethod

@@ -1414,3 +1414,111 @@ def gated_update_tail(agg: torch.Tensor, center: torch.Tensor, residual: torch.T
     return _GatedUpdateTail.apply(agg, center, residual, lin_ih.weight, lin_ih.bias, lin_hh.weight, lin_hh.bias,
                                   lin_self.weight, lin_self.bias, out_proj.weight, out_proj.bias, p,
                                   _fresh_seed() if p > 0.0 else 0)
+
+
+# --------------------------------------------------------------------------------------------
+# Per-timestep tokens broadcast over agents
+# --------------------------------------------------------------------------------------------
+# The reference writes these as broadcasting torch.where / add / expand.  Their gradients with respect
+# to the tokens are sums over the agent axis of a [T, N, D] tensor, which the framework computes with a
+# multi-block reduction that clears its semaphores through a runtime memset -- a node kind that takes no
+# effect in a replayed HIP graph on this stack.  Here the sums run on hivt_rowsum_by_code (fixed order).
+_step_codes = {}
+
+
+def _codes(steps: int, n: int, device) -> torch.Tensor:
+    """int32 [steps * n]: row s * n + j carries code s."""
+    key = (steps, n, device)
+    if key not in _step_codes:
+        if len(_step_codes) > 64:
+            _step_codes.clear()
+        _step_codes[key] = torch.arange(steps, dtype=torch.int32, device=device).repeat_interleave(n)
+    return _step_codes[key]
+
+
+def _rowsum_by_code(x2: torch.Tensor, codes: torch.Tensor, num_codes: int) -> torch.Tensor:
+    m, n = x2.shape
+    out = torch.empty(num_codes, n, dtype=torch.float32, device=x2.device)
+    ws = _workspace(_lib.query("hivt_rowsum_by_code_workspace_bytes", m, n, num_codes), x2.device)
+    _lib.call("hivt_rowsum_by_code", _p(x2), x2.stride(0), _p(codes), m, n, num_codes, _p(out), _p(ws), ws.numel(),
+              _stream(x2))
+    return out
+
+
+def step_tokens_supported(x: torch.Tensor, steps: int) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] <= 128 and steps <= 32 \
+        and x.numel() > 0
+
+
+class _MaskedStepTokens(torch.autograd.Function):
+    """``where(mask[..., None], token[:, None, :], x)`` for x [T, N, D], mask [T, N], token [T, D]
+    (``models/local_encoder.py:150,230``)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, token):
+        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x)
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        t, n, d = dy.shape
+        dy = dy.contiguous()
+        dx = torch.where(mask.unsqueeze(-1), torch.zeros((), dtype=dy.dtype, device=dy.device), dy) \
+            if ctx.needs_input_grad[0] else None
+        dtoken = None
+        if ctx.needs_input_grad[2]:
+            codes = torch.where(mask.reshape(-1), _codes(t, n, dy.device), -1)
+            dtoken = _rowsum_by_code(dy.view(t * n, d), codes, t)
+        return dx, None, dtoken
+
+
+def masked_step_tokens(x: torch.Tensor, mask: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
+    """Rows (t, n) with ``mask[t, n]`` replaced by ``token[t]``; x [T, N, D], mask [T, N] bool, token [T, D]."""
+    return _MaskedStepTokens.apply(x, mask, token)
+
+
+class _AppendTokenAddSteps(torch.autograd.Function):
+    """``cat((x, last.expand(1, N, D))) + per_step[:, None, :]`` for x [T, N, D], last [D], per_step [T + 1, D]
+    (the class token and the positional embedding of ``models/local_encoder.py:231-232``)."""
+
+    @staticmethod
+    def forward(ctx, x, last, per_step):
+        t, n, d = x.shape
+        out = torch.empty(t + 1, n, d, dtype=x.dtype, device=x.device)
+        torch.add(x, per_step[:t].unsqueeze(1), out=out[:t])
+        out[t] = last + per_step[t]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        s, n, d = dy.shape
+        dy = dy.contiguous()
+        dper = _rowsum_by_code(dy.view(s * n, d), _codes(s, n, dy.device), s)
+        return dy[:s - 1], dper[s - 1].clone(), dper
+
+
+def append_token_add_steps(x: torch.Tensor, last: torch.Tensor, per_step: torch.Tensor) -> torch.Tensor:
+    return _AppendTokenAddSteps.apply(x, last, per_step)
+
+
+def step_guards(nan_check: Optional[torch.Tensor], finite_check: Optional[torch.Tensor],
+                extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """0-d device bool: ``nan_check`` holds a NaN, ``finite_check`` a NaN or an infinity, or ``extra`` (a
+    device bool) is set -- the step's guards (``models/hivt.py:264,272,294``) in three small launches and
+    without a multi-block framework reduction."""
+    ref = nan_check if nan_check is not None else finite_check
+    _need_gpu(ref)
+    a = nan_check.contiguous() if nan_check is not None else None
+    b = finite_check.contiguous() if finite_check is not None else None
+    for t in (a, b):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("step_guards checks float32 tensors")
+    ex = extra.view(torch.uint8) if (extra is not None and extra.dtype == torch.bool) else extra
+    flag = torch.empty(1, dtype=torch.int32, device=ref.device)
+    _lib.call("hivt_step_guards", _p(a), a.numel() if a is not None else 0, _p(b), b.numel() if b is not None else 0,
+              _p(ex), _p(flag), _stream(ref))
+    return flag.view(torch.bool)[0]

@@ -154,8 +154,9 @@ class GanTrainer:
             return self.model.training_step(data, self.opt_g, self.opt_d, sync)
         data["edge_capacity"] = self.edge_capacity
         logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
-        over = data["edge_plan"].overflow.to(torch.int64)
-        self._overflows = over if self._overflows is None else self._overflows + over
+        if self._overflows is None:
+            self._overflows = torch.zeros((), dtype=torch.int64, device=data["edge_plan"].overflow.device)
+        self._overflows.add_(data["edge_plan"].overflow)  # in place: a recorded step keeps counting when replayed
         return logs
 
     def tune(self, run_step, rounds: int = 2, steps: int = 4) -> Dict[str, bool]:

@@ -338,10 +338,12 @@ int hivt_laplace_minmode_bwd(const float* grad_losses, const float* y_hat, const
 
 size_t hivt_rowsum_by_code_workspace_bytes(int64_t M, int32_t N, int32_t R);
 
-/* out[r][c] = sum over rows m with index[m] == r of x[m][c], for R <= 16 codes and N <= 128 columns,
- * summed in a fixed order.  It is the gradient of the table handed to hivt_linear_fwd through
- * add / add_index (x = gradient at the pre-normalisation sum), replacing the scatter of per-edge
- * gradients into the categorical embedding parameters. */
+/* out[r][c] = sum over rows m with index[m] == r of x[m][c], for R <= 32 codes and N <= 128 columns,
+ * summed in a fixed order; rows whose index is outside [0, R) (e.g. -1) are left out.  It is the gradient
+ * of the table handed to hivt_linear_fwd through add / add_index (x = gradient at the pre-normalisation
+ * sum), replacing the scatter of per-edge gradients into the categorical embedding parameters, and the
+ * gradient of per-timestep tokens broadcast over agents (bos_token, padding_token, pos_embed, cls_token:
+ * models/local_encoder.py:150,230-232). */
 int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* index, int64_t M, int32_t N, int32_t R,
                         float* out, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
@@ -444,6 +446,13 @@ int hivt_hinge_r1_fwd(const float* s_real, const float* grad_norm2, const float*
 int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_fake, const float* w,
                       const float* count, int64_t B, float lambda_r1, float* g_real, float* g_norm2, float* g_fake,
                       hivt_stream_t stream);
+
+/* Guards of the training step in one pass (models/hivt.py:264,272,294): flag[0] = 1 if nan_check holds a
+ * NaN, finite_check holds a NaN or an infinity, or *extra != 0 (extra: optional device byte, e.g. an
+ * overflow flag); else 0.  flag is a device int32 written in full by every call (its first byte read as a
+ * bool is the guard).  Either array may be NULL / empty. */
+int hivt_step_guards(const float* nan_check, int64_t n_nan, const float* finite_check, int64_t n_finite,
+                     const uint8_t* extra, int32_t* flag, hivt_stream_t stream);
 
 /* AdamW update of `count` float32 tensors (torch.optim.AdamW as the reference configures it,
  * models/hivt.py:444,453: decoupled weight decay, no amsgrad):
