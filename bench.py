@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the extra timing of the step with the other --matmul precision")
     ap.add_argument("--no-tune", action="store_true", help="keep the default launch schedule (no timing of alternatives)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every step eagerly instead of replaying the recorded step (single-GPU runs record the "
+                         "step into a HIP graph by default; data-parallel runs always launch eagerly)")
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
     ap.add_argument("--cpu-scenes", type=int, default=8)
@@ -176,18 +179,32 @@ def main():
         pool.append((b, b["y"]))
     # capacities of the filtered edge lists, measured once over the pool with 10 % head room: with them
     # the step needs no host read-back (live counts, guards and the overflow flag stay on the device)
-    capacity = None if args.host_guards else hv.GanTrainer.calibrate(model, [b for b, _ in pool]).edge_capacity
+    spec = None if args.host_guards else hv.GanTrainer.calibrate(model, [b for b, _ in pool])
+    capacity = spec.edge_capacity if spec is not None else None
     trainer = hv.GanTrainer(model, edge_capacity=capacity)
     torch.manual_seed(1000 + rank)  # dropout streams differ per rank
 
-    def run_step(i: int):
+    def eager_step(i: int):
         batch, y_raw = pool[i % len(pool)]
         batch["y"] = y_raw            # forward rotates the targets in place on the batch object
         batch["edge_plan"] = None     # edge construction belongs to the step
         return trainer.step(batch)
 
     # launch schedule chosen by measurement (untimed set-up, like the capacity calibration above)
-    tuned = trainer.tune(run_step) if not args.no_tune else {}
+    tuned = trainer.tune(eager_step) if not args.no_tune else {}
+    graphed = None
+    if world == 1 and spec is not None and not args.no_graph:
+        # the whole step recorded once and replayed: batches padded to one fixed shape (inert padding), each
+        # step copies its batch into the recording's input tensors (device to device) and launches the graph
+        from hivt_gan_amd.graph import GraphedStep
+        padded = [hv.pad_batch(b, spec) for b, _ in pool]
+        graphed = GraphedStep(trainer, spec, padded[0], critic_streams=bool(tuned.get("critic_streams", False)))
+
+    def run_step(i: int):
+        if graphed is not None:
+            return graphed.run(padded[i % len(padded)])
+        return eager_step(i)
+
     for i in range(args.warmup):
         run_step(i)
     def timed(first: int, steps: int) -> float:
@@ -209,10 +226,19 @@ def main():
         return float(t.item())
 
     records = []
-    ops.SEG_ATTN_TIMING = records
+    if graphed is None:
+        ops.SEG_ATTN_TIMING = records
     elapsed = timed(args.warmup, args.steps)
     ops.SEG_ATTN_TIMING = None
-    logs = timed.logs
+    logs = {k: v.clone() for k, v in timed.logs.items()}
+    if graphed is not None:
+        # a replayed graph cannot carry the per-kernel time stamps: the edge-attention kernels are priced on
+        # the same number of eagerly launched steps of the same trainer right after the timed region
+        ops.SEG_ATTN_TIMING = records
+        for i in range(args.steps):
+            eager_step(args.warmup + i)
+        torch.cuda.synchronize()
+        ops.SEG_ATTN_TIMING = None
 
     # the same step with the other operand precision of the dense products, timed the same way after the
     # headline measurement (reported beside it, never as ``value``)
@@ -220,6 +246,8 @@ def main():
     if not args.no_variant:
         name = "bf16" if args.matmul == "fp32" else "fp32"
         ops.set_matmul_precision(name)
+        if graphed is not None:
+            graphed.record()  # the operand precision is part of what a recording fixes
         for i in range(3):
             run_step(i)
         other = (name, timed(args.warmup + args.steps, args.steps))
@@ -262,6 +290,11 @@ def main():
                                    + ("bf16 dense products" if args.matmul == "bf16" else "fp32"),
                        "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
                        "guards": "host" if args.host_guards else "device",
+                       "launch": ("one recorded HIP graph per step (%d kernel + %d copy nodes), inputs copied into its "
+                                  "static tensors" % (graphed.nodes.get("kernel", 0), graphed.nodes.get("memcpy", 0)))
+                       if graphed is not None else "eager",
+                       "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
+                       if graphed is not None else "kernel time stamps inside the timed region",
                        "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,
                        "precision": "fp32 throughout" if args.matmul == "fp32" else
                        "dense products on the bf16 matrix instructions with fp32 accumulation: forward products on "

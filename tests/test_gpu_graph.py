@@ -1,0 +1,97 @@
+"""The training step recorded into a HIP graph (``GraphedStep``) against the same steps launched eagerly:
+identical parameters after several steps, a tripped guard that leaves the model untouched, fresh dropout
+masks on every replay, and no runtime memset node in the recording."""
+import pytest
+import torch
+
+import hivt_gan_amd as hv
+from hivt_gan_amd import ops
+from hivt_gan_amd.graph import GraphedStep
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def make(dropout, lr=5e-4, critic_lr=1e-4, weight_decay=1e-4):
+    torch.manual_seed(11)
+    m = hv.HiVT(embed_dim=64, num_heads=8, dropout=dropout, use_gan=True, num_temporal_layers=2, num_global_layers=2,
+                lr=lr, critic_lr=critic_lr, weight_decay=weight_decay).to(DEV)
+    m.train()
+    if dropout == 0.0:
+        for critic in m.critics.values():
+            for mod in critic.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+    return m
+
+
+def batches_and_spec(model, count=3, scenes=5):
+    raw = [hv.make_batch(scenes, first_index=400 + 10 * i).to(DEV) for i in range(count)]
+    spec = hv.GanTrainer.calibrate(model, raw)
+    return [hv.pad_batch(b, spec) for b in raw], spec
+
+
+def eager_run(model, spec, padded, order):
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    for i in order:
+        b = padded[i].clone()
+        logs = trainer.step(b)
+    return trainer, logs
+
+
+def test_replayed_steps_equal_eager_steps():
+    order = [0, 1, 2, 1]
+    ref_model = make(0.0)
+    padded, spec = batches_and_spec(ref_model)
+    # eager reference: the recording's three warm-up steps and its captured step run on padded[0] eagerly too
+    # (capture executes nothing), then the replays
+    eager_run(ref_model, spec, padded, [0, 0, 0] + order)
+    model = make(0.0)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    step = GraphedStep(trainer, spec, padded[0], warmup=3)
+    assert step.nodes.get("memset", 0) == 0 and step.nodes.get("kernel", 0) > 100, step.nodes
+    for i in order:
+        logs = step.run(padded[i])
+    torch.cuda.synchronize()
+    assert float(logs["skipped"]) == 0.0
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
+        assert torch.equal(a, b), f"{k} differs between replayed and eager steps"
+    assert trainer.overflowed_steps() == 0
+
+
+def test_tripped_guard_in_a_replay_leaves_the_model_untouched():
+    model = make(0.0)
+    padded, spec = batches_and_spec(model, count=2)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    step = GraphedStep(trainer, spec, padded[0])
+    step.run(padded[1])
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    poisoned = padded[0].clone()
+    poisoned["y"][3, 2, 0] = float("nan")
+    logs = step.run(poisoned)
+    torch.cuda.synchronize()
+    assert float(logs["skipped"]) == 1.0
+    for k, v in model.state_dict().items():
+        if k.endswith("_u") or k.endswith("_v"):  # the power iteration of the critics' forward passes still ran
+            continue
+        assert torch.equal(v, before[k]), k
+    logs = step.run(padded[1])
+    assert float(logs["skipped"]) == 0.0
+
+
+def test_every_replay_draws_new_dropout_masks():
+    # learning rates and weight decay 0: the parameters stay put, so only the masks can change the losses
+    model = make(0.1, lr=0.0, critic_lr=0.0, weight_decay=0.0)
+    padded, spec = batches_and_spec(model, count=1)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    step = GraphedStep(trainer, spec, padded[0])
+    seen = []
+    for _ in range(3):
+        seen.append(float(step.run(padded[0])["reg_loss"]))
+    assert len(set(seen)) == 3, seen
+    model0 = make(0.0, lr=0.0, critic_lr=0.0, weight_decay=0.0)
+    trainer0 = hv.GanTrainer(model0, distributed=False, edge_capacity=spec.edge_capacity)
+    step0 = GraphedStep(trainer0, spec, padded[0])
+    same = [float(step0.run(padded[0])["reg_loss"]) for _ in range(3)]
+    assert len(set(same)) == 1, same
+    assert ops.DEVICE_SEED is None  # the recording hands the seed scalar back
