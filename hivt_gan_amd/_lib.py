@@ -22,6 +22,9 @@ SIGNATURES = {
     "hivt_edges_temporal": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32,
                                     c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_edges_radius": (c_int, [_P, c_int64, _P, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hivt_edges_all_pairs_workspace_bytes": (c_size_t, [c_int64]),
+    "hivt_edges_all_pairs_csr": (c_int, [_P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_float,
+                                         c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_csr_build": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_build_static": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P]),

@@ -190,6 +190,117 @@ int run_filter(const Pred& pred, int64_t items, int32_t* src_out, int32_t* dst_o
   return HIVT_OK;
 }
 
+// ---- all-pairs edges straight into CSR -------------------------------------------------------
+// The reference's candidate list is every ordered pair of agents of a scene (nuscenes_dataset.py:139-141),
+// so the filtered, target-grouped edge set of a timestep can be produced from the agents themselves:
+// row (t, i) holds the sources j of i's scene, ascending, with j != i, both valid at t and (optionally)
+// within the radius -- exactly the stable target-sort of the reference's filtered COO list.  No candidate
+// list is read, nothing is sorted: degrees, a two-level scan, an ordered fill.
+constexpr int kPairThreads = 256;
+
+struct PairArgs {
+  const int32_t* scene_range;  // [N][2]: first agent of i's scene, one past its last
+  const uint8_t* pm;
+  int64_t pm_stride;
+  const float* pos;
+  int64_t pos_sn, pos_st;
+  int32_t N, t0, T;
+  float radius;
+};
+
+__device__ __forceinline__ bool pair_kept(const PairArgs& a, int32_t t, int32_t j, const float2& pi, float2& attr) {
+  if (a.pm[(int64_t)j * a.pm_stride + t]) return false;
+  const float2 pj = *reinterpret_cast<const float2*>(a.pos + (int64_t)j * a.pos_sn + (int64_t)t * a.pos_st);
+  attr.x = pj.x - pi.x;
+  attr.y = pj.y - pi.y;
+  if (a.radius > 0.0f) {
+    // same rounding as the host framework's 2-norm over a pair: sqrt(fma(y, y, fl(x*x)))
+    const float d2 = __fmaf_rn(attr.y, attr.y, __fmul_rn(attr.x, attr.x));
+    return __fsqrt_rn(d2) < a.radius;
+  }
+  return true;
+}
+
+// deg[r] for row r = tt * N + i, and the sum of every block's 256 rows.
+__global__ __launch_bounds__(kPairThreads) void pairs_degree_kernel(const PairArgs a, int64_t rows,
+                                                                    int32_t* __restrict__ deg,
+                                                                    int32_t* __restrict__ block_totals) {
+  __shared__ int wave_tot[kPairThreads / kWave];
+  const int64_t r = (int64_t)blockIdx.x * kPairThreads + threadIdx.x;
+  int cnt = 0;
+  if (r < rows) {
+    const int32_t tt = (int32_t)(r / a.N), i = (int32_t)(r - (int64_t)tt * a.N), t = a.t0 + tt;
+    if (!a.pm[(int64_t)i * a.pm_stride + t]) {
+      const int32_t lo = a.scene_range[2 * i], hi = a.scene_range[2 * i + 1];
+      const float2 pi = *reinterpret_cast<const float2*>(a.pos + (int64_t)i * a.pos_sn + (int64_t)t * a.pos_st);
+      for (int32_t j = lo; j < hi; ++j) {
+        float2 attr;
+        if (j != i && pair_kept(a, t, j, pi, attr)) ++cnt;
+      }
+    }
+    deg[r] = cnt;
+  }
+  const int w = wave_sum_i(cnt);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kPairThreads / kWave; ++k) s += wave_tot[k];
+    block_totals[blockIdx.x] = s;
+  }
+}
+
+// rowptr[r] holds deg[r] on entry and the (capacity-clamped) exclusive prefix on exit; every row then
+// writes its edges in ascending source order.  Entries that would land at or beyond `capacity` are dropped
+// (the caller sees total > capacity in count_out and discards the batch).
+__global__ __launch_bounds__(kPairThreads) void pairs_fill_kernel(const PairArgs a, int64_t rows, int64_t capacity,
+                                                                  const int32_t* __restrict__ block_offsets,
+                                                                  const int32_t* __restrict__ total,
+                                                                  int32_t* __restrict__ rowptr,
+                                                                  int32_t* __restrict__ src_out,
+                                                                  int32_t* __restrict__ dst_out,
+                                                                  float* __restrict__ attr_out) {
+  __shared__ int wave_tot[kPairThreads / kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * kPairThreads + threadIdx.x;
+  const int d = r < rows ? rowptr[r] : 0;
+  // inclusive scan inside the wave, then across the block's four waves
+  int incl = d;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int wave_off = 0;
+#pragma unroll
+  for (int k = 0; k < kPairThreads / kWave; ++k)
+    if (k < wave) wave_off += wave_tot[k];
+  int64_t base = (int64_t)block_offsets[blockIdx.x] + wave_off + incl - d;
+  if (r < rows) rowptr[r] = (int32_t)(base < capacity ? base : capacity);
+  if (r == rows - 1) {
+    const int64_t tot = *total;
+    rowptr[rows] = (int32_t)(tot < capacity ? tot : capacity);
+  }
+  if (r >= rows || d == 0) return;
+  const int32_t tt = (int32_t)(r / a.N), i = (int32_t)(r - (int64_t)tt * a.N), t = a.t0 + tt;
+  const int32_t lo = a.scene_range[2 * i], hi = a.scene_range[2 * i + 1];
+  const float2 pi = *reinterpret_cast<const float2*>(a.pos + (int64_t)i * a.pos_sn + (int64_t)t * a.pos_st);
+  for (int32_t j = lo; j < hi; ++j) {
+    float2 attr;
+    if (j != i && pair_kept(a, t, j, pi, attr)) {
+      if (base < capacity) {
+        src_out[base] = j + tt * a.N;
+        dst_out[base] = i + tt * a.N;
+        *reinterpret_cast<float2*>(attr_out + 2 * base) = attr;
+      }
+      ++base;
+    }
+  }
+}
+
 // ---- CSR build ------------------------------------------------------------------------------
 // `count` (optional, device memory) holds the number of meaningful entries when the list is padded
 // to a fixed capacity E; entries at or beyond it are ignored.
@@ -309,6 +420,52 @@ extern "C" int hivt_edges_radius(const int64_t* edge_index, int64_t E0, const fl
   RadiusPred pred{edge_index, E0, edge_attr, radius};
   return run_filter(pred, E0, src_out, dst_out, attr_out, count_out, workspace, workspace_bytes,
                     (hipStream_t)stream, what);
+}
+
+extern "C" size_t hivt_edges_all_pairs_workspace_bytes(int64_t rows) {
+  const int64_t blocks = (rows + kPairThreads - 1) / kPairThreads;
+  return align_up((size_t)(2 * align_up((size_t)(blocks > 0 ? blocks : 1), 64)) * sizeof(int32_t), 256);
+}
+
+extern "C" int hivt_edges_all_pairs_csr(const int32_t* scene_range, const uint8_t* padding_mask, int64_t pm_stride,
+                                        const float* positions, int64_t pos_stride_n, int64_t pos_stride_t,
+                                        int32_t N, int32_t t0, int32_t T, float radius, int64_t capacity,
+                                        int32_t* rowptr, int32_t* src_out, int32_t* dst_out, float* attr_out,
+                                        int32_t* count_out, void* workspace, size_t workspace_bytes,
+                                        hivt_stream_t stream_) {
+  const char* what = "hivt_edges_all_pairs_csr";
+  hipStream_t stream = (hipStream_t)stream_;
+  HIVT_REQUIRE(N >= 0 && T >= 0 && t0 >= 0 && capacity >= 0, HIVT_ERR_ARG, "%s: negative size", what);
+  const int64_t rows = (int64_t)N * T;
+  HIVT_REQUIRE(rows < (int64_t)1 << 31 && capacity < (int64_t)1 << 31, HIVT_ERR_ARG,
+               "%s: %lld rows / capacity %lld exceed int32 indexing", what, (long long)rows, (long long)capacity);
+  HIVT_REQUIRE(rowptr != nullptr && count_out != nullptr, HIVT_ERR_ARG, "%s: rowptr / count_out is null", what);
+  if (rows == 0) {
+    zero_words(rowptr, 1, stream);
+    zero_words(count_out, 1, stream);
+    HIVT_CHECK_LAUNCH(what);
+    return HIVT_OK;
+  }
+  HIVT_REQUIRE(scene_range && padding_mask && positions, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(capacity == 0 || (src_out && dst_out && attr_out), HIVT_ERR_ARG, "%s: null output", what);
+  HIVT_REQUIRE(pos_stride_t % 2 == 0 && pos_stride_n % 2 == 0, HIVT_ERR_ARG,
+               "%s: position strides must be even (8-byte aligned pairs)", what);
+  HIVT_REQUIRE(workspace != nullptr && workspace_bytes >= hivt_edges_all_pairs_workspace_bytes(rows),
+               HIVT_ERR_WORKSPACE, "%s: workspace too small", what);
+  const int64_t blocks = (rows + kPairThreads - 1) / kPairThreads;
+  int32_t* block_totals = reinterpret_cast<int32_t*>(workspace);
+  int32_t* block_offsets = block_totals + align_up((size_t)blocks, 64);
+  PairArgs a{scene_range, padding_mask, pm_stride, positions, pos_stride_n, pos_stride_t, N, t0, T, radius};
+  hipLaunchKernelGGL(pairs_degree_kernel, dim3((unsigned)blocks), dim3(kPairThreads), 0, stream, a, rows, rowptr,
+                     block_totals);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, block_totals, blocks, block_offsets,
+                     count_out);
+  HIVT_CHECK_LAUNCH(what);
+  hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)blocks), dim3(kPairThreads), 0, stream, a, rows, capacity,
+                     block_offsets, count_out, rowptr, src_out, dst_out, attr_out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
 }
 
 extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {

@@ -83,6 +83,19 @@ class TemporalData:
         return "TemporalData(" + ", ".join(parts) + ")"
 
 
+def _is_all_pairs(scene: TemporalData) -> bool:
+    """Whether ``edge_index`` is every ordered pair (j, i), j != i, of the scene's agents in source-major
+    order (``itertools.permutations``, nuscenes_dataset.py:139-141)."""
+    n = int(scene.num_nodes)
+    ei = scene["edge_index"]
+    if ei.shape[1] != n * (n - 1):
+        return False
+    ar = torch.arange(n)
+    src, dst = ar.repeat_interleave(n), ar.repeat(n)
+    keep = src != dst
+    return bool(torch.equal(ei[0], src[keep]) and torch.equal(ei[1], dst[keep]))
+
+
 def collate(scenes: List[TemporalData]) -> TemporalData:
     """Batch scenes with the offsets of ``Batch.from_data_list`` for this data class."""
     if len(scenes) == 0:
@@ -117,6 +130,12 @@ def collate(scenes: List[TemporalData]) -> TemporalData:
             out[k] = list(vals)
     batch_vec = torch.cat([torch.full((int(s.num_nodes),), i, dtype=torch.long) for i, s in enumerate(scenes)])
     out["batch"] = batch_vec
+    # per agent: first agent of its scene and one past its last (what the device-side edge builder walks),
+    # and whether every scene's candidate list is all ordered pairs, as the reference's preprocessor writes
+    # them (nuscenes_dataset.py:139-141) -- only then may the builder stand in for the list
+    out["scene_range"] = torch.cat([torch.tensor([[o, o + int(s.num_nodes)]], dtype=torch.int32).expand(int(s.num_nodes), 2)
+                                    for o, s in zip(node_offs, scenes)]).contiguous()
+    out["all_pairs"] = all(_is_all_pairs(s) for s in scenes)
     out["_num_graphs"] = len(scenes)
     return TemporalData(**out)
 
@@ -361,18 +380,20 @@ def pad_batch(batch: TemporalData, spec: BatchSpec, out: Optional[TemporalData] 
     lai[:, :la] = batch["lane_actor_index"]
     fields["lane_actor_index"] = lai
     fields["lane_actor_vectors"] = _pad_rows(batch["lane_actor_vectors"], spec.num_lane_actor, _FAR)
+    if "scene_range" in batch:  # padded agents belong to no scene: an empty range
+        fields["scene_range"] = _pad_rows(batch["scene_range"], spec.num_nodes, 0)
     if out is None:
         out = TemporalData(**fields)
         out["num_nodes"] = spec.num_nodes
         out["_num_graphs"] = batch.num_graphs
         out["edge_capacity"] = spec.edge_capacity
-        for k in ("agent_index", "av_index"):
+        for k in ("agent_index", "av_index", "all_pairs"):
             if k in batch:
                 out[k] = batch[k]
         return out
     for k, v in fields.items():
         out[k].copy_(v)
-    for k in ("agent_index", "av_index"):
+    for k in ("agent_index", "av_index", "all_pairs"):
         if k in batch:
             out[k] = batch[k]
     return out

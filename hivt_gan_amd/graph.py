@@ -26,7 +26,7 @@ _SEED_STRIDE = 0x51342543DE82EF95
 
 # tensors of a padded batch that a step reads
 _INPUT_KEYS = ("x", "positions", "y", "padding_mask", "bos_mask", "rotate_angles", "lane_vectors", "is_intersections",
-               "turn_directions", "traffic_controls", "edge_index", "lane_actor_index", "lane_actor_vectors")
+               "turn_directions", "traffic_controls", "edge_index", "lane_actor_index", "lane_actor_vectors", "scene_range")
 
 
 _HIP_NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
@@ -126,6 +126,8 @@ class GraphedStep:
     def load(self, batch: TemporalData) -> None:
         """Copies a batch padded to the same ``BatchSpec`` into the static inputs."""
         for k in _INPUT_KEYS:
+            if k not in self.static:
+                continue
             dst = self._y if k == "y" else self.static[k]
             src = batch[k]
             if src.shape != dst.shape:

@@ -64,21 +64,59 @@ def subgraph(subset: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tens
     return torch.stack([src[:e], dst[:e]]).long(), None
 
 
-def build_edge_plan(data, historical_steps: int, local_radius: Optional[float]) -> EdgePlan:
+def _pair_sets(data, T: int, n: int, local_radius: Optional[float], caps):
+    """Agent-agent sets (all history steps, last-step interaction) straight in CSR order from the agents
+    themselves; ``caps`` = capacities of the two lists."""
+    out = []
+    for (t0, steps, radius), cap in zip(((0, T, local_radius), (T - 1, 1, None)), caps):
+        rowptr, src, dst, attr, count = ops.edges_all_pairs_csr(data["scene_range"], data["padding_mask"],
+                                                                data["positions"], t0, steps, radius, cap)
+        out.append((rowptr, src, dst, attr, count, steps * n))
+    return out
+
+
+def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], from_pairs: Optional[bool] = None
+                    ) -> EdgePlan:
     """All three edge sets of a batch, filtered and CSR-grouped on the device.
 
     Without ``data["edge_capacity"]`` the three live counts are read back once and the lists are cut
     to size.  With it (three integers, see ``BatchSpec``) nothing is read back: the lists keep their
     fixed capacity, every consumer takes the live count from device memory, and ``overflow`` records on
-    the device whether a filtered list did not fit (the step must then be discarded)."""
+    the device whether a filtered list did not fit (the step must then be discarded).
+
+    Batches whose candidate list is every ordered pair of a scene's agents (``data["all_pairs"]``, set by
+    ``collate``) get their two agent-agent sets from ``hivt_edges_all_pairs_csr``: no candidate list is
+    read and nothing is sorted; other batches go through the order-preserving filter of the given list
+    and a stable sort by target.  Both give the same sets in the same order.  ``from_pairs`` forces one
+    route (tests)."""
     T = historical_steps
     n = int(data.num_nodes)
     num_lanes = int(data["lane_vectors"].shape[0])
-    aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
+    caps = data.get("edge_capacity")
+    if from_pairs is None:
+        from_pairs = bool(data.get("all_pairs", False)) and "scene_range" in data
     la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
+    if from_pairs:
+        e0 = int(data["edge_index"].shape[1])
+        pair_caps = (min(int(caps[0]), e0 * T), min(int(caps[2]), e0)) if caps is not None else (e0 * T, e0)
+        aa, gi = _pair_sets(data, T, n, local_radius, pair_caps)
+        if caps is None:
+            counts = torch.cat([aa[4], la[3], gi[4]]).cpu()  # the only host synchronisation of the forward pass
+            c_aa, c_la, c_gi = (int(c) for c in counts)
+            sets = [EdgeSet(T * n, T * n, aa[1][:c_aa], aa[2][:c_aa], aa[3][:c_aa], aa[0], None, aa[1][:c_aa], aa[2][:c_aa]),
+                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n),
+                    EdgeSet(n, n, gi[1][:c_gi], gi[2][:c_gi], gi[3][:c_gi], gi[0], None, gi[1][:c_gi], gi[2][:c_gi])]
+            return EdgePlan(*sets)
+        c_la = min(int(caps[1]), int(la[0].shape[0]))
+        sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4].clamp(max=pair_caps[0])),
+                ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3].clamp(max=c_la)),
+                EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4].clamp(max=pair_caps[1]))]
+        counts = torch.cat([aa[4], la[3], gi[4]])
+        overflow = (aa[4] > pair_caps[0]) | (la[3] > c_la) | (gi[4] > pair_caps[1])
+        return EdgePlan(*sets, overflow=overflow.view(()), counts=counts)
+    aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
     gi = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], T - 1, 1, None)
     shapes = ((T * n, T * n), (num_lanes, n), (n, n))
-    caps = data.get("edge_capacity")
     if caps is None:
         counts = torch.cat([aa[3], la[3], gi[3]]).cpu()  # the only host synchronisation of the forward pass
         sets = [ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd)

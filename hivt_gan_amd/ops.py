@@ -128,20 +128,56 @@ def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = 
     return rowptr, perm
 
 
+def edges_all_pairs_csr(scene_range: torch.Tensor, padding_mask: torch.Tensor, positions: torch.Tensor, t0: int,
+                        T: int, radius: Optional[float], capacity: int
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Agent-agent edges of timesteps ``t0..t0+T-1`` for all-pairs candidate sets, produced in CSR order
+    without a candidate list or a sort.  Returns ``rowptr`` (int32 [T*N + 1], clamped to ``capacity``),
+    ``src``, ``dst`` (int32 [capacity], ids offset by ``(t-t0)*N``), ``attr`` (float [capacity, 2]) and the
+    device int32 ``count`` of kept edges before clamping."""
+    _need_gpu(scene_range, padding_mask, positions)
+    if scene_range.dtype != torch.int32 or scene_range.dim() != 2 or scene_range.shape[1] != 2:
+        raise ValueError("scene_range must be int32 [N, 2]")
+    sr = scene_range.contiguous()
+    pm = padding_mask.contiguous()
+    pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
+    pos = positions.contiguous()
+    if pos.dtype != torch.float32 or pos.dim() != 3 or pos.shape[2] != 2:
+        raise ValueError("positions must be float32 [N, steps, 2]")
+    n = pos.shape[0]
+    if sr.shape[0] != n or pm.shape[0] != n:
+        raise ValueError("scene_range, padding_mask and positions must describe the same agents")
+    if t0 < 0 or t0 + T > pm.shape[1] or t0 + T > pos.shape[1]:
+        raise ValueError("timestep range outside padding_mask / positions")
+    dev = pos.device
+    cap = max(int(capacity), 1)
+    rowptr = torch.empty(n * T + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(cap, dtype=torch.int32, device=dev)
+    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _workspace(_lib.query("hivt_edges_all_pairs_workspace_bytes", n * T), dev)
+    _lib.call("hivt_edges_all_pairs_csr", _p(sr), _p(pm), pm.stride(0), _p(pos), pos.stride(0), pos.stride(1), n, t0, T,
+              float(radius) if radius is not None else 0.0, int(capacity), _p(rowptr), _p(src), _p(dst), _p(attr),
+              _p(count), _p(ws), ws.numel(), _stream(pos))
+    return rowptr, src, dst, attr, count
+
+
 @dataclass
 class EdgeSet:
     """One filtered edge list grouped by target node.
 
     ``coo_*`` are in the order the reference would hold them (filtered, order preserving);
     ``src`` / ``dst`` are the same edges in CSR order (position i of the CSR order is position
-    ``perm[i]`` of the COO order)."""
+    ``perm[i]`` of the COO order).  A set produced directly in CSR order has ``perm`` None and its
+    ``coo_*`` lists already grouped by target."""
     num_src: int
     num_dst: int
     coo_src: torch.Tensor
     coo_dst: torch.Tensor
     coo_attr: torch.Tensor
     rowptr: torch.Tensor
-    perm: torch.Tensor
+    perm: Optional[torch.Tensor]
     src: Optional[torch.Tensor] = None
     dst: Optional[torch.Tensor] = None
     rowptr_by_src: Optional[torch.Tensor] = None

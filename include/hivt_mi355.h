@@ -73,6 +73,27 @@ int hivt_edges_radius(const int64_t* edge_index, int64_t E0, const float* edge_a
                       int32_t* src_out, int32_t* dst_out, float* attr_out, int32_t* count_out,
                       void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
+/* Workspace for hivt_edges_all_pairs_csr over rows = N * T target rows. */
+size_t hivt_edges_all_pairs_workspace_bytes(int64_t rows);
+
+/* Per-timestep agent-agent edges of timesteps t0 .. t0+T-1 produced DIRECTLY in CSR order, for batches
+ * whose candidate list is every ordered pair of agents of a scene, which is what the reference's
+ * preprocessor writes (nuscenes_dataset.py:139-141).  Same edge set, attributes and order as
+ * hivt_edges_temporal followed by hivt_csr_build over the targets -- i.e. as subgraph + positions
+ * difference + DistanceDropEdge (models/local_encoder.py:58-61, utils.py:69-78; t0 = T_hist-1, T = 1,
+ * radius <= 0: models/global_interactor.py:48-50) followed by torch_geometric's grouping by target --
+ * without reading a candidate list and without a sort: row (t, i) lists the sources j of i's scene in
+ * ascending order.
+ *   scene_range int32 [N,2]: first agent of agent i's scene and one past its last;
+ *   rowptr int32 [N*T + 1]; src_out / dst_out int32 [capacity] (node ids (t-t0)*N + n), attr_out float
+ *   [capacity,2]; count_out int32 [1] = number of kept edges BEFORE clamping.  If it exceeds `capacity`
+ *   the lists hold the first `capacity` edges, rowptr is clamped to it, and the caller discards the batch. */
+int hivt_edges_all_pairs_csr(const int32_t* scene_range, const uint8_t* padding_mask, int64_t pm_stride,
+                             const float* positions, int64_t pos_stride_n, int64_t pos_stride_t, int32_t N,
+                             int32_t t0, int32_t T, float radius, int64_t capacity, int32_t* rowptr,
+                             int32_t* src_out, int32_t* dst_out, float* attr_out, int32_t* count_out,
+                             void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+
 /* Workspace for hivt_csr_build. */
 size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows);
 

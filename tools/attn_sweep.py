@@ -39,7 +39,8 @@ def main():
     kw = dict(num_agents=200, num_lanes=1000, all_valid=True, local_radius=150.0) if args.dense else {}
     batch = hv.make_batch(args.scenes if not args.dense else min(args.scenes, 4), **kw).to(dev)
     plan = build_edge_plan(batch, 20, 150.0 if args.dense else 50.0)
-    plan.interaction.src = plan.interaction.coo_src.index_select(0, plan.interaction.perm.long())
+    gi = plan.interaction
+    gi.src = gi.coo_src if gi.perm is None else gi.coo_src.index_select(0, gi.perm.long())
     torch.manual_seed(0)
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
