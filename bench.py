@@ -78,9 +78,44 @@ def measured_traffic(embed_dim: int, scenes: int):
     return best
 
 
+class _Phases:
+    """Exclusive wall time per phase of the CPU step: the oracle's functions are wrapped in place, nested
+    calls are charged to the innermost phase."""
+
+    def __init__(self):
+        import collections
+        self.seconds = collections.defaultdict(float)
+        self._stack = []
+        self._undo = []
+
+    def wrap(self, owner, name, phase):
+        orig = getattr(owner, name)
+
+        def timed_call(*a, **k):
+            self._stack.append([time.perf_counter(), 0.0])
+            try:
+                return orig(*a, **k)
+            finally:
+                start, child = self._stack.pop()
+                elapsed = time.perf_counter() - start
+                self.seconds[phase] += elapsed - child
+                if self._stack:
+                    self._stack[-1][1] += elapsed
+
+        setattr(owner, name, timed_call)
+        self._undo.append((owner, name, orig))
+
+    def restore(self):
+        for owner, name, orig in reversed(self._undo):
+            setattr(owner, name, orig)
+        self._undo = []
+
+
 def cpu_baseline(embed_dim: int, scenes: int, steps: int):
     """The CPU oracle's G + D + R1 step (forward, both backwards, both AdamW updates) on a bounded
-    sample of the same workload; returns scenes/sec on the host cores torch is allowed to use."""
+    sample of the same workload; returns scenes/sec on the host cores torch is allowed to use and the
+    time per phase (edge construction, the three edge-attention stages, temporal encoder, decoder, losses,
+    backward passes, optimizers)."""
     from oracle import hivt_oracle as O
     cfg = model_config(embed_dim)
     torch.manual_seed(2022)
@@ -98,6 +133,17 @@ def cpu_baseline(embed_dim: int, scenes: int, steps: int):
     opt_g = torch.optim.AdamW(gen_params, lr=cfg["lr"], weight_decay=cfg["weight_decay"])
     opt_d = torch.optim.AdamW(cr_params, lr=cfg["critic_lr"], weight_decay=0.0)
     ocfg = dict(cfg)
+    phases = _Phases()
+    for name in ("temporal_edges", "distance_drop_edge", "subgraph"):
+        phases.wrap(O, name, "edge_build")
+    for name, phase in (("aa_encoder", "aa_encoder"), ("temporal_encoder", "temporal_encoder"), ("al_encoder", "al_encoder"),
+                        ("global_interactor", "global_interactor"), ("mlp_decoder", "decoder"),
+                        ("supervised_losses", "losses"), ("discriminator_loss", "losses"),
+                        ("generator_adv_loss", "losses")):
+        phases.wrap(O, name, phase)
+    phases.wrap(torch.autograd, "grad", "backward")
+    phases.wrap(opt_g, "step", "optimizers")
+    phases.wrap(opt_d, "step", "optimizers")
 
     def critic_update(grads):
         for p, g in zip(cr_params, grads.values()):
@@ -106,19 +152,27 @@ def cpu_baseline(embed_dim: int, scenes: int, steps: int):
 
     ocfg["critic_update"] = critic_update
     times = []
-    for i in range(steps + 1):
-        batch = hv.make_batch(scenes, first_index=50_000 + i * scenes)
-        data = {k: batch[k] for k in batch.keys()}
-        t0 = time.perf_counter()
-        res = O.gan_step_grads(gen_sd, cr_sd, data, ocfg, training=True)
-        for p, k in zip(gen_params, [k for k, v in gen_sd.items() if v.requires_grad]):
-            p.grad = res["g_grads"][k]
-        opt_g.step()
-        times.append(time.perf_counter() - t0)
-    med = statistics.median(times[1:])  # first step is warm-up
+    try:
+        for i in range(steps + 1):
+            batch = hv.make_batch(scenes, first_index=50_000 + i * scenes)
+            data = {k: batch[k] for k in batch.keys()}
+            if i == 1:
+                phases.seconds.clear()  # the first step is warm-up
+            t0 = time.perf_counter()
+            res = O.gan_step_grads(gen_sd, cr_sd, data, ocfg, training=True)
+            for p, k in zip(gen_params, [k for k, v in gen_sd.items() if v.requires_grad]):
+                p.grad = res["g_grads"][k]
+            opt_g.step()
+            times.append(time.perf_counter() - t0)
+    finally:
+        phases.restore()
+    med = statistics.median(times[1:])
+    per_phase = {k: round(v / steps * 1e3, 1) for k, v in sorted(phases.seconds.items(), key=lambda kv: -kv[1])}
+    per_phase["other"] = round(max(sum(times[1:]) / steps * 1e3 - sum(per_phase.values()), 0.0), 1)
     return {"value": scenes / med, "unit": "scenes/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} timed steps (+1 warm-up) of the CPU oracle's G+D+R1 step incl. AdamW on {scenes} "
-                      f"synthetic scenes, HiVT-{embed_dim} fp32, median {med * 1e3:.0f} ms/step"}
+                      f"synthetic scenes per step, HiVT-{embed_dim} fp32, median {med * 1e3:.0f} ms/step",
+            "phase_ms_per_step": per_phase}
 
 
 def main():
@@ -144,8 +198,8 @@ def main():
                          "step into a HIP graph by default; data-parallel runs always launch eagerly)")
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
-    ap.add_argument("--cpu-scenes", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-scenes", type=int, default=128, help="scenes per step of the CPU baseline (the GPU step's batch)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
