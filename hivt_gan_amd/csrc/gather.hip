@@ -45,9 +45,13 @@ __global__ __launch_bounds__(256) void gather_rotate_fwd_kernel(
 __global__ __launch_bounds__(256) void gather_rotate_bwd_kernel(
     const float* __restrict__ d_out, const float* __restrict__ rot, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, const int32_t* __restrict__ perm, int32_t rot_mod, int64_t E,
-    const int32_t* __restrict__ count, float* __restrict__ d_attr, float* __restrict__ d_x) {
+    const int32_t* __restrict__ count, float* __restrict__ d_attr, float* __restrict__ d_x_edge) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E || (count != nullptr && e >= *count)) return;
+  if (e >= E) return;
+  if (count != nullptr && e >= *count) {
+    if (d_x_edge) *reinterpret_cast<float4*>(d_x_edge + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int64_t p = perm ? perm[e] : e;
   const float4 g = *reinterpret_cast<const float4*>(d_out + 4 * e);
   float2 gx = make_float2(g.x, g.y), ga = make_float2(g.z, g.w);
@@ -58,11 +62,9 @@ __global__ __launch_bounds__(256) void gather_rotate_bwd_kernel(
     ga = make_float2(g.z * r.x + g.w * r.y, g.z * r.z + g.w * r.w);
   }
   if (d_attr) *reinterpret_cast<float2*>(d_attr + 2 * p) = ga;
-  if (d_x) {
-    const int32_t s = src[p];
-    atomicAdd(d_x + 2 * (int64_t)s, gx.x);
-    atomicAdd(d_x + 2 * (int64_t)s + 1, gx.y);
-  }
+  // the contribution of this edge to the gradient of its source row; the caller adds the rows of one
+  // source in a fixed order (hivt_segment_sum_rows over a CSR by source), so no float atomics are needed
+  if (d_x_edge) *reinterpret_cast<float4*>(d_x_edge + 4 * e) = make_float4(gx.x, gx.y, 0.f, 0.f);
 }
 
 __global__ __launch_bounds__(256) void relpose_fwd_kernel(const float* __restrict__ attr, const float* __restrict__ rot,
@@ -120,14 +122,15 @@ extern "C" int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride,
 
 extern "C" int hivt_edge_gather_rotate_bwd(const float* d_out, const float* rot, const int32_t* src,
                                            const int32_t* dst, const int32_t* perm, int32_t rot_mod, int64_t E,
-                                           const int32_t* count, float* d_attr, float* d_x, hivt_stream_t stream) {
+                                           const int32_t* count, float* d_attr, float* d_x_edge,
+                                           hivt_stream_t stream) {
   const char* what = "hivt_edge_gather_rotate_bwd";
   HIVT_REQUIRE(E >= 0, HIVT_ERR_ARG, "%s: negative edge count", what);
-  if (E == 0 || (d_attr == nullptr && d_x == nullptr)) return HIVT_OK;
+  if (E == 0 || (d_attr == nullptr && d_x_edge == nullptr)) return HIVT_OK;
   HIVT_REQUIRE(d_out && src && dst, HIVT_ERR_ARG, "%s: null pointer", what);
   HIVT_REQUIRE(rot == nullptr || rot_mod > 0, HIVT_ERR_ARG, "%s: rot_mod must be positive", what);
   hipLaunchKernelGGL(gather_rotate_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     d_out, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, count, d_attr, d_x);
+                     d_out, rot, src, dst, perm, rot_mod > 0 ? rot_mod : 1, E, count, d_attr, d_x_edge);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

@@ -223,7 +223,7 @@ class _EdgeGatherRotate(torch.autograd.Function):
         dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
         _lib.call("hivt_edge_gather_rotate_fwd", _p(x2), x2.stride(0), _p(attr), _p(rot_c), _p(src), _p(dst), _p(perm),
                   int(rot_mod), e, _p(count), _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
-        ctx.save_for_backward(rot_c, src, dst, perm, count)
+        ctx.save_for_backward(rot_c, src, dst, perm, count, src_csr)
         ctx.rot_mod = int(rot_mod)
         ctx.x_shape = tuple(x_src.shape)
         ctx.mark_non_differentiable(src_csr, dst_csr)
@@ -232,21 +232,27 @@ class _EdgeGatherRotate(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out, _g1, _g2):
-        rot_c, src, dst, perm, count = ctx.saved_tensors
+        rot_c, src, dst, perm, count, src_out = ctx.saved_tensors
         e = src.shape[0]
         d_out = d_out.contiguous()
-        d_x = torch.zeros(ctx.x_shape[0], 2, dtype=torch.float32, device=d_out.device) if ctx.needs_input_grad[0] \
-            else None
+        dev = d_out.device
+        d_x_edge = torch.empty(e, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         d_attr = None
         if ctx.needs_input_grad[1]:
-            d_attr = (torch.zeros if count is not None else torch.empty)(e, 2, dtype=torch.float32, device=d_out.device)
-        if d_x is not None or d_attr is not None:
+            d_attr = (torch.zeros if count is not None else torch.empty)(e, 2, dtype=torch.float32, device=dev)
+        if d_x_edge is not None or d_attr is not None:
             _lib.call("hivt_edge_gather_rotate_bwd", _p(d_out), _p(rot_c), _p(src), _p(dst), _p(perm), ctx.rot_mod, e,
-                      _p(count), _p(d_attr), _p(d_x), _stream(d_out))
-        if d_x is not None and ctx.x_shape[1] != 2:
-            full = torch.zeros(ctx.x_shape, dtype=torch.float32, device=d_out.device)
-            full[:, :2] = d_x
-            d_x = full
+                      _p(count), _p(d_attr), _p(d_x_edge), _stream(d_out))
+        d_x = None
+        if d_x_edge is not None:
+            # rows of one source summed in ascending output position: deterministic
+            ns = ctx.x_shape[0]
+            rowptr_s, perm_s = csr_build(src_out, ns, count)
+            summed = torch.empty(ns, 4, dtype=torch.float32, device=dev)
+            _lib.call("hivt_segment_sum_rows", _p(d_x_edge), 4, 4, _p(rowptr_s), _p(perm_s), ns, _p(summed), 4,
+                      _stream(d_out))
+            d_x = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dev)
+            d_x[:, :2] = summed[:, :2]
         return d_x, d_attr, None, None, None, None, None, None
 
 

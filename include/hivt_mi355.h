@@ -140,12 +140,14 @@ int hivt_edge_gather_rotate_fwd(const float* x_src, int64_t x_stride, const floa
                                 int64_t E, const int32_t* count, float* out, int32_t* src_csr, int32_t* dst_csr,
                                 hivt_stream_t stream);
 
-/* Gradient of the above w.r.t. attr (d_attr, original edge order, may be NULL) and x_src
- * (d_x float [Ns,2], must be zero-filled by the caller, accumulated with float atomics, may be
- * NULL).  Needed only when positions / features require grad (never in the reference's step). */
+/* Gradient of the above w.r.t. attr (d_attr float [E,2], original edge order, may be NULL) and, per edge,
+ * w.r.t. the gathered source row (d_x_edge float [E,4] in OUTPUT order: the two components, then two zeros;
+ * may be NULL).  The gradient of x_src is the sum of the d_x_edge rows of each source, which the caller
+ * takes with hivt_segment_sum_rows over a CSR by source (width 4): a fixed summation order, no float
+ * atomics.  Needed only when positions / features require grad (never in the reference's step). */
 int hivt_edge_gather_rotate_bwd(const float* d_out, const float* rot, const int32_t* src, const int32_t* dst,
                                 const int32_t* perm, int32_t rot_mod, int64_t E, const int32_t* count,
-                                float* d_attr, float* d_x, hivt_stream_t stream);
+                                float* d_attr, float* d_x_edge, hivt_stream_t stream);
 
 /* Relative pose features of GlobalInteractor.forward (models/global_interactor.py:54-58):
  * out[e] = [ attr[p] @ R[dst[p]],  cos(theta[src[p]]-theta[dst[p]]),  sin(...) ], p = perm[e]. */

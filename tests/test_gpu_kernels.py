@@ -162,7 +162,12 @@ def test_gather_rotate_and_relpose():
     (out * w.to(DEV)).sum().backward()
     (ref * w).sum().backward()
     close(ag.grad, ac.grad)
-    close(xg.grad, xc.grad, rtol=1e-4)  # float atomics: order-dependent rounding
+    close(xg.grad, xc.grad)  # rows of one source summed in a fixed order (no float atomics)
+    first = xg.grad.clone()
+    xg.grad = None
+    out_again, _, _ = ops.edge_gather_rotate(xg, ag, rot.to(DEV), src.to(DEV), dst.to(DEV), perm, nd)
+    (out_again * w.to(DEV)).sum().backward()
+    assert torch.equal(xg.grad, first), "the source-row gradient must be bit-reproducible"
     # no rotation
     out2, _, _ = ops.edge_gather_rotate(x.to(DEV), attr.to(DEV), None, src.to(DEV), dst.to(DEV), perm, 1)
     assert torch.equal(out2.cpu(), torch.cat([x[src.long()[p]], attr[p]], dim=-1))
