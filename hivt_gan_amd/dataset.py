@@ -56,7 +56,25 @@ def sanitize(data: TemporalData) -> TemporalData:
             data["edge_index"] = ei.reshape(2, 1)
         elif ei.dim() != 2 or ei.size(0) != 2:
             raise ValueError(f"Bad edge_index shape: {tuple(ei.shape)}")
+    check_index_ranges(data)
     return data
+
+
+def check_index_ranges(data: TemporalData) -> None:
+    """Index fields must address existing agents / lanes: the device kernels index with them unchecked,
+    where the reference's host-side indexing would raise.  Raises ``ValueError``."""
+    n = int(data["num_nodes"]) if "num_nodes" in data else None
+    if n is not None and "edge_index" in data and data["edge_index"].numel() > 0:
+        ei = data["edge_index"]
+        if int(ei.min()) < 0 or int(ei.max()) >= n:
+            raise ValueError(f"edge_index entries must lie in [0, {n}); found [{int(ei.min())}, {int(ei.max())}]")
+    if "lane_actor_index" in data and torch.is_tensor(data["lane_actor_index"]) and data["lane_actor_index"].numel() > 0:
+        lai = data["lane_actor_index"]
+        num_lanes = int(data["lane_vectors"].shape[0]) if "lane_vectors" in data else None
+        if num_lanes is not None and (int(lai[0].min()) < 0 or int(lai[0].max()) >= num_lanes):
+            raise ValueError(f"lane_actor_index lane ids must lie in [0, {num_lanes})")
+        if n is not None and (int(lai[1].min()) < 0 or int(lai[1].max()) >= n):
+            raise ValueError(f"lane_actor_index actor ids must lie in [0, {n})")
 
 
 _PLAIN = (int, float, str, bool, type(None))

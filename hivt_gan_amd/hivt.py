@@ -56,6 +56,10 @@ class HiVT(nn.Module):
         # sync_free: the guards of the training step stay on the device (no host read-back, no
         # data-dependent control flow), so the host can keep launching ahead of the GPU
         self.sync_free = bool(kwargs.get("sync_free", False))
+        # global-norm clipping of the supervised (non-GAN) step; the reference sets 0.5 on its Trainer
+        # (train.py:76), where it reaches only that step: the GAN step optimises manually and is not clipped
+        clip = kwargs.get("gradient_clip_val", 0.5)
+        self.gradient_clip_val = float(clip) if clip else 0.0
 
         self.local_encoder = LocalEncoder(historical_steps=historical_steps, node_dim=node_dim, edge_dim=edge_dim,
                                           embed_dim=embed_dim, num_heads=num_heads, dropout=dropout,
@@ -250,21 +254,37 @@ class HiVT(nn.Module):
     def _losses_and_updates(self, data, y_hat, pi, opt_g, opt_d, sync_grads, bad) -> Dict[str, torch.Tensor]:
         found_inf = bad.float() if bad is not None else None
 
-        def update(group: str, opt: torch.optim.Optimizer) -> None:
+        def arm(group: str) -> None:
+            # a data-parallel reducer that overlaps its collectives with the backward pass wants to know
+            # before the pass starts
+            if sync_grads is not None and hasattr(sync_grads, "begin"):
+                sync_grads.begin(group, bad)
+
+        def update(group: str, opt: torch.optim.Optimizer, clip: bool = False) -> None:
             if sync_grads is not None:
-                sync_grads(group, bad)
+                share = sync_grads(group, bad)
+                if bad is not None and torch.is_tensor(share):
+                    # every rank discarded its batch: skip the update as the single-process step does
+                    opt.found_inf = (share == 0).to(torch.float32)
             elif found_inf is not None:
                 opt.found_inf = found_inf  # read by the fused AdamW kernels: 1 leaves parameters and state untouched
+            if clip and self.gradient_clip_val:
+                # the supervised step is clipped by global norm, after the data-parallel average and before
+                # the update, as the reference's Trainer(gradient_clip_val=0.5) does for automatic
+                # optimisation (train.py:76); device-side, no read-back
+                torch.nn.utils.clip_grad_norm_([p for g in opt.param_groups for p in g["params"] if p.grad is not None],
+                                               self.gradient_clip_val, foreach=True)
             opt.step()
 
         reg_loss, cls_loss, best_mode = self._supervised_losses(data, y_hat, pi)
         logs: Dict[str, torch.Tensor] = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
 
-        if not self.use_gan:  # Case A, models/hivt.py:270-285 (gradient clipping is the caller's business)
+        if not self.use_gan:  # Case A, models/hivt.py:270-285
             loss = reg_loss + cls_loss
             opt_g.zero_grad(set_to_none=True)
+            arm("generator")
             loss.backward()
-            update("generator", opt_g)
+            update("generator", opt_g, clip=True)
             logs["loss"] = loss.detach()
             return logs
 
@@ -273,6 +293,7 @@ class HiVT(nn.Module):
         for _ in range(self.critic_steps):  # models/hivt.py:305-314
             d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
             opt_d.zero_grad(set_to_none=True)
+            arm("critic")
             d_loss.backward()
             if real.is_cuda:
                 join_critic_streams(real.device)
@@ -285,6 +306,7 @@ class HiVT(nn.Module):
             g_adv, g_logs = self.g_loss_fn.forward_masked(self.critics, fake, keep)
             g_total = reg_loss + cls_loss + g_adv
             opt_g.zero_grad(set_to_none=True)
+            arm("generator")
             g_total.backward()
             if fake.is_cuda:
                 join_critic_streams(fake.device)

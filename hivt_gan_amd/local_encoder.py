@@ -333,7 +333,10 @@ class TemporalEncoderLayer(nn.Module):
             o = ops.temporal_attention(qkv, H, mha.dropout, self.training)
             return ops.fused_linear(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p,
                                     training=self.training, residual=residual)
-        # stock path (CPU tensors, unsupported shapes): fused SDPA kernel of the framework
+        if x.is_cuda:
+            raise ops._unsupported(f"causal attention over {S} steps at width {D} with {H} heads "
+                                   "(at most 32 steps; head widths 4, 8, 16, 32)")
+        # CPU tensors: the framework's attention
         qkv = F.linear(x, mha.in_proj_weight, mha.in_proj_bias).view(S, N, 3, H, D // H)
         q, k, v = (qkv[:, :, i].permute(1, 2, 0, 3) for i in range(3))  # [N, H, S, d]
         o = F.scaled_dot_product_attention(q, k, v, dropout_p=mha.dropout if self.training else 0.0, is_causal=True)

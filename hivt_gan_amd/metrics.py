@@ -30,16 +30,28 @@ class _MeanMetric:
             self.total += total
             self.count += count
 
-    def sync(self, group=None) -> None:
-        """Adds the states of all ranks (no-op outside an initialised process group)."""
-        if self.total is not None and dist.is_available() and dist.is_initialized():
-            pair = torch.stack([self.total, self.count])
+    def _pair(self, device) -> torch.Tensor:
+        """(total, count) as a float64 pair on ``device``; zeros for a metric that has seen nothing."""
+        if self.total is None:
+            return torch.zeros(2, dtype=torch.float64, device=device)
+        return torch.stack([self.total, self.count]).to(device)
+
+    def sync(self, group=None, device=None) -> None:
+        """Adds the states of all ranks (no-op outside an initialised process group).  A rank whose
+        metric has seen nothing -- no validation batch, or only batches the metric ignores -- still enters
+        the collective, with zeros."""
+        if dist.is_available() and dist.is_initialized():
+            if device is None:
+                device = self.total.device if self.total is not None else (
+                    torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")
+            pair = self._pair(device)
             dist.all_reduce(pair, group=group)
             self.total, self.count = pair[0], pair[1]
 
     def compute(self) -> torch.Tensor:
         if self.total is None:
             return torch.tensor(float("nan"))
+        # no sample anywhere: NaN (0 / 0), never an exception
         return (self.total / self.count).to(torch.float32)
 
 
@@ -124,9 +136,20 @@ class ValidationMetrics:
         for m in self._all().values():
             m.reset()
 
-    def sync(self, group=None) -> None:
-        for m in self._all().values():
-            m.sync(group)
+    def sync(self, group=None, device=None) -> None:
+        """ONE collective for all seven metrics: every rank stacks its (total, count) pairs -- zeros where a
+        metric has seen nothing on this rank -- so the ranks cannot fall out of step with each other."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        metrics = list(self._all().values())
+        if device is None:
+            seen = [m.total.device for m in metrics if m.total is not None]
+            device = seen[0] if seen else (torch.device("cuda", torch.cuda.current_device())
+                                           if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        packed = torch.stack([m._pair(device) for m in metrics])
+        dist.all_reduce(packed, group=group)
+        for m, pair in zip(metrics, packed):
+            m.total, m.count = pair[0].clone(), pair[1].clone()
 
     def compute(self) -> Dict[str, torch.Tensor]:
         return {k: m.compute() for k, m in self._all().items()}

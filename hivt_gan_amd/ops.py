@@ -28,6 +28,18 @@ def _stream(t: torch.Tensor):
     return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
+class UnsupportedShapeError(NotImplementedError):
+    """A GPU tensor whose shape no kernel of the library is built for.  The library does not quietly hand
+    such a tensor to the framework's operators: a model outside the built shapes (embed_dim above 128 for
+    the LayerNorm kernels, a temporal sequence above 32 steps, ...) must fail visibly, not run a different
+    code path."""
+
+
+def _unsupported(what: str) -> "UnsupportedShapeError":
+    return UnsupportedShapeError(f"hivt_gan_amd has no kernel for {what}; the library does not fall back to the "
+                                 "framework's operators on GPU tensors")
+
+
 def _need_gpu(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -45,7 +57,7 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
         raise TypeError(f"expected float32, got {t.dtype}")
     if t.dim() != 2:
         raise ValueError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
-    if t.shape[0] > 1 and t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0:
+    if (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.data_ptr() % 16 != 0:
         t = t.contiguous()
     return t
 
@@ -787,10 +799,13 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
-    """``norm(x)`` over the last dimension on the streaming LayerNorm kernels (width <= 128); wider rows
-    and CPU tensors go to the framework's implementation."""
-    if not x.is_cuda or x.shape[-1] > 128 or x.dtype != torch.float32 or x.numel() == 0:
+    """``norm(x)`` over the last dimension on the streaming LayerNorm kernels (width <= 128).  CPU tensors
+    (and empty ones) go to the framework's implementation; a GPU tensor the kernels are not built for
+    raises ``UnsupportedShapeError``."""
+    if not x.is_cuda or x.numel() == 0:
         return norm(x)
+    if x.shape[-1] > 128 or x.dtype != torch.float32:
+        raise _unsupported(f"LayerNorm over {x.shape[-1]} columns of {x.dtype} (float32, at most 128)")
     return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)[0]
 
 
@@ -798,8 +813,10 @@ def layer_norm_residual(x: torch.Tensor, norm: torch.nn.LayerNorm) -> Tuple[torc
     """``(norm(x), x)`` for a pre-norm block ``x + block(norm(x))``: feed the first to the block and use the
     second as the residual operand, and the backward pass sums the two gradient routes inside the
     LayerNorm-backward kernel."""
-    if not x.is_cuda or x.shape[-1] > 128 or x.dtype != torch.float32 or x.numel() == 0:
+    if not x.is_cuda or x.numel() == 0:
         return norm(x), x
+    if x.shape[-1] > 128 or x.dtype != torch.float32:
+        raise _unsupported(f"LayerNorm over {x.shape[-1]} columns of {x.dtype} (float32, at most 128)")
     return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
 
 
@@ -812,21 +829,12 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     [codes <= 16, N] and row m adds ``add[add_index[m]]``.  Dropout (active when ``training``) and the
     residual are part of the plain epilogues only (no ``layer_norm``).
 
-    Falls back to the stock GPU ops only where no kernel exists for the shape (LayerNorm wider than
-    128 columns); CPU tensors are refused."""
+    CPU tensors are refused; a LayerNorm epilogue wider than 128 columns raises ``UnsupportedShapeError``."""
     _need_gpu(x, weight)
     n = weight.shape[0]
     p = float(dropout_p) if training else 0.0
     if not linear_fused_supported(n, layer_norm is not None):
-        y = torch.nn.functional.linear(x, weight, bias)
-        if add is not None:
-            y = y + (add if add_index is None else add.index_select(0, add_index.long()))
-        if layer_norm is not None:
-            y = layer_norm(y)
-        y = torch.relu(y) if relu else y
-        if p > 0.0:
-            y = torch.nn.functional.dropout(y, p, True)
-        return y if residual is None else residual + y
+        raise _unsupported(f"a Linear + LayerNorm epilogue over {n} columns (at most 128)")
     gamma = layer_norm.weight if layer_norm is not None else None
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0

@@ -41,31 +41,149 @@ def _all_reduce_sum_via_host(t: torch.Tensor, group=None) -> None:
 
 
 class FlatGradBucket:
-    """Gradients of a parameter group packed into one contiguous buffer for one all-reduce.
+    """Gradients of a parameter group in one contiguous buffer, reduced in a few chunks.
 
-    After a backward the group's gradients are gathered with a single concatenation (parameters
-    without a gradient contribute zeros), reduced, and handed back to the parameters as views of the
-    reduced buffer, so the optimizer reads the averaged values without further copies."""
+    The buffer holds the group's gradients in parameter order plus one trailing element, the share of
+    ranks that contributed (1 - bad, averaged).  ``chunks`` partitions the parameters in the order their
+    gradients become ready during backward (decoder first, agent-agent encoder last).  With ``overlap``
+    every chunk is packed and handed to an asynchronous all-reduce from a post-accumulate hook as soon
+    as its last gradient has arrived, so the collective runs beside the rest of the backward pass;
+    ``finish`` packs what is left, waits, and hands the reduced values back to the parameters as views
+    of the buffer.  Without ``overlap`` everything happens in ``finish``: one pack, one all-reduce."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]) -> None:
+    def __init__(self, params: Iterable[torch.nn.Parameter], chunks: Optional[List[List[torch.nn.Parameter]]] = None,
+                 overlap: bool = False, group=None) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
+        self.total = sum(self.sizes)
+        self.group = group
+        self.overlap = bool(overlap)
         self.flat: Optional[torch.Tensor] = None
-        self._zeros = {}
+        offsets, off = {}, 0
+        for p, n in zip(self.params, self.sizes):
+            offsets[id(p)] = off
+            off += n
+        if chunks is None:
+            chunks = [self.params]
+        own = {id(p) for p in self.params}
+        chunks = [[p for p in c if id(p) in own] for c in chunks]
+        chunks = [c for c in chunks if c]
+        flat_order = [id(p) for c in chunks for p in c]
+        if flat_order != [id(p) for p in self.params]:
+            raise ValueError("chunks must list the group's parameters in the group's order")
+        self.chunks = []  # (first element, one past the last, parameters)
+        for c in chunks:
+            a = offsets[id(c[0])]
+            self.chunks.append((a, a + sum(p.numel() for p in c), c))
+        self._chunk_of = {id(p): i for i, (_, _, c) in enumerate(self.chunks) for p in c}
+        self._pending: List[int] = []
+        self._packed: List[bool] = []
+        self._next = -1
+        self._work: list = []
+        self._bad: Optional[torch.Tensor] = None
+        self._armed = False
+        self._hooks = []
+        if self.overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _zero_like(self, p: torch.nn.Parameter) -> torch.Tensor:
-        key = (p.numel(), p.device, p.dtype)
-        if key not in self._zeros:
-            self._zeros[key] = torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
-        return self._zeros[key]
+    # ------------------------------------------------------------------------------------------
+    def _buffer(self) -> torch.Tensor:
+        if self.flat is None or self.flat.device != self.params[0].device:
+            self.flat = torch.zeros(self.total + 1, dtype=self.params[0].dtype, device=self.params[0].device)
+        return self.flat
+
+    def begin(self, bad: Optional[torch.Tensor] = None) -> None:
+        """Call before the backward pass whose gradients this bucket reduces.  ``bad`` (device bool): this
+        rank's contribution is replaced by zeros (selected, not multiplied, so non-finite gradients cannot
+        leak into the sum)."""
+        self._buffer()
+        self._bad = bad
+        self._pending = [len(c) for _, _, c in self.chunks]
+        self._packed = [False] * len(self.chunks)
+        self._next = len(self.chunks) - 1
+        self._work = []
+        self._armed = True
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._armed:
+            return
+        self._pending[self._chunk_of[id(p)]] -= 1
+        self._launch_ready(force=False)
+
+    def _launch_ready(self, force: bool) -> None:
+        """Collectives are issued in ONE order on every rank -- last chunk first, the order the backward pass
+        completes them -- whatever order the gradients of this rank arrive in (a rank that discarded its
+        batch has no backward pass at all): a chunk goes out once every chunk behind it has gone out and
+        its own gradients are complete (or ``force``: the backward pass is over)."""
+        while self._next >= 0 and (force or self._pending[self._next] == 0):
+            i = self._next
+            if not self._packed[i]:
+                self._pack_chunk(i)
+            self._reduce(i, async_op=not force)
+            self._next -= 1
+
+    def _pack_chunk(self, i: int) -> None:
+        a, b, params = self.chunks[i]
+        piece = self.flat[a:b]
+        base, item = self.flat.data_ptr(), self.flat.element_size()
+        offs, off = [], a
+        for p in params:
+            offs.append(off)
+            off += p.numel()
+        # a gradient that is still the view handed back by the last unpack (zeroed in place, never replaced:
+        # a rank that discarded its batch) already sits where it belongs
+        in_place = [p.grad is not None and p.grad.data_ptr() == base + o * item for p, o in zip(params, offs)]
+        if not any(in_place) and all(p.grad is not None for p in params):
+            torch.cat([p.grad.reshape(-1) for p in params], out=piece)
+        else:
+            for p, o, same in zip(params, offs, in_place):
+                if same:
+                    continue
+                n = p.numel()
+                if p.grad is None:
+                    self.flat[o:o + n].zero_()
+                else:
+                    self.flat[o:o + n].copy_(p.grad.reshape(-1))
+        if self._bad is not None:
+            piece.masked_fill_(self._bad, 0.0)
+        if i == len(self.chunks) - 1:  # the contribution flag travels with the last chunk
+            if self._bad is not None:
+                self.flat[self.total:] = 1.0 - self._bad.to(self.flat.dtype)
+            else:
+                self.flat[self.total:] = 1.0
+        self._packed[i] = True
+
+    def _span(self, i: int) -> torch.Tensor:
+        a, b, _ = self.chunks[i]
+        return self.flat[a:b + 1] if i == len(self.chunks) - 1 else self.flat[a:b]
+
+    def _reduce(self, i: int, async_op: bool) -> None:
+        piece = self._span(i)
+        if _is_rccl(self.group):  # RCCL averages inside the collective
+            work = dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        elif piece.is_cuda:  # CPU backend with device tensors: staged through host memory
+            _all_reduce_sum_via_host(piece, self.group)
+            piece.div_(dist.get_world_size(self.group))
+            work = None
+        else:
+            work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if not async_op:
+                piece.div_(dist.get_world_size(self.group))
+            else:
+                work = (work, piece)
+        if async_op and work is not None:
+            self._work.append(work)
 
     def pack(self, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``bad`` (device bool): this rank's contribution is replaced by zeros (selected, not
-        multiplied, so non-finite gradients cannot leak into the sum)."""
-        self.flat = torch.cat([p.grad.reshape(-1) if p.grad is not None else self._zero_like(p) for p in self.params])
-        if bad is not None:
-            self.flat = torch.where(bad, torch.zeros((), dtype=self.flat.dtype, device=self.flat.device), self.flat)
-        return self.flat
+        """Packs every chunk that is not packed yet (nothing is reduced); returns the gradient part of the
+        buffer."""
+        if not self._armed:
+            self.begin(bad)
+        for i in range(len(self.chunks)):
+            if not self._packed[i]:
+                self._pack_chunk(i)
+        return self.flat[:self.total]
 
     def unpack(self) -> None:
         off = 0
@@ -73,17 +191,45 @@ class FlatGradBucket:
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
-    def all_reduce_mean(self, group=None, bad: Optional[torch.Tensor] = None) -> None:
-        self.pack(bad)
-        if _is_rccl(group):  # RCCL averages inside the collective
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
-        else:
-            if self.flat.is_cuda:
-                _all_reduce_sum_via_host(self.flat, group)
+    def finish(self, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """After the backward pass: reduces whatever has not been handed to a collective yet, waits for all
+        of them and installs the averaged gradients.  Returns the share of ranks that contributed (a device
+        scalar; 0 means that every rank discarded its batch)."""
+        if not self._armed:
+            self.begin(bad)
+        self._launch_ready(force=True)
+        for work in self._work:
+            if isinstance(work, tuple):  # CPU backend: the sum still has to become a mean
+                work[0].wait()
+                work[1].div_(dist.get_world_size(self.group))
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+                work.wait()
+        self._work = []
+        self._armed = False
         self.unpack()
+        return self.flat[self.total]
+
+    def all_reduce_mean(self, group=None, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.finish(bad)
+
+
+class _DataParallelSync:
+    """What ``HiVT.training_step`` calls around each backward pass: ``begin`` before it (arms the bucket's
+    hooks), the object itself after it (returns the share of contributing ranks)."""
+
+    def __init__(self, trainer: "GanTrainer") -> None:
+        self.trainer = trainer
+
+    def begin(self, group: str, bad: Optional[torch.Tensor] = None) -> None:
+        self.trainer.buckets[group].begin(bad)
+
+    def __call__(self, group: str, bad: Optional[torch.Tensor] = None):
+        return self.trainer._sync(group, bad)
+
+
+# scalar entries of the step's logs, in the order they are packed for the one reduction per step
+_LOG_KEYS = ("reg_loss", "cls_loss", "loss", "d_loss", "g_adv", "g_total", "d_loss_short", "r1_short", "d_loss_mid",
+             "r1_mid", "d_loss_long", "r1_long", "g_loss_short", "g_loss_mid", "g_loss_long", "skipped")
 
 
 class GanTrainer:
@@ -95,11 +241,13 @@ class GanTrainer:
     ``overflowed_steps()``."""
 
     def __init__(self, model: HiVT, distributed: Optional[bool] = None,
-                 edge_capacity: Optional[Tuple[int, int, int]] = None) -> None:
+                 edge_capacity: Optional[Tuple[int, int, int]] = None, overlap: Optional[bool] = None,
+                 sync_logs: bool = True) -> None:
         self.model = model
         self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
             if distributed is None else distributed
         self.edge_capacity = tuple(int(c) for c in edge_capacity) if edge_capacity is not None else None
+        self.sync_logs = bool(sync_logs)
         if self.edge_capacity is not None:
             if not next(model.parameters()).is_cuda:
                 raise RuntimeError("the read-back-free step needs the model on the GPU")
@@ -113,10 +261,20 @@ class GanTrainer:
         self.buckets: Dict[str, FlatGradBucket] = {}
         if self.distributed:
             self.broadcast_state()
+            overlap = _is_rccl() if overlap is None else bool(overlap)
             gen = model.generator_parameters() if model.use_gan else list(model.parameters())
-            self.buckets["generator"] = FlatGradBucket(gen)
+            # chunks in the order the backward pass finishes them: decoder, interaction module, lane
+            # and temporal stages, agent-agent stage (the buffer keeps the optimizer's parameter order,
+            # local encoder first, so the chunk list is walked from the back of the buffer)
+            le = model.local_encoder
+            chunks = [list(le.aa_encoder.parameters()), list(le.temporal_encoder.parameters())
+                      + list(le.al_encoder.parameters()), list(model.global_interactor.parameters()),
+                      list(model.decoder.parameters())]
+            if not model.use_gan or [id(p) for c in chunks for p in c] != [id(p) for p in gen if p.requires_grad]:
+                chunks = None
+            self.buckets["generator"] = FlatGradBucket(gen, chunks=chunks, overlap=overlap)
             if model.use_gan:
-                self.buckets["critic"] = FlatGradBucket(model.critic_parameters())
+                self.buckets["critic"] = FlatGradBucket(model.critic_parameters(), overlap=overlap)
         self._overflows: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------------------------
@@ -145,15 +303,39 @@ class GanTrainer:
             else:
                 dist.broadcast(t.data, src=0)
 
-    def _sync(self, group: str, bad: Optional[torch.Tensor] = None) -> None:
-        self.buckets[group].all_reduce_mean(bad=bad)
+    def _sync(self, group: str, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.buckets[group].finish(bad)
+
+    def reduce_logs(self, logs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The step's scalar logs averaged over the ranks that produced them, in ONE all-reduce (the
+        reference logs every key with ``sync_dist=True``, one reduction each, ``models/hivt.py:332-340``).
+        A rank that skipped its batch takes part with weight zero, so every rank enters the collective."""
+        ref = next(iter(logs.values()))
+        vals = torch.zeros(2 * len(_LOG_KEYS), dtype=torch.float32, device=ref.device)
+        present = [i for i, k in enumerate(_LOG_KEYS) if k in logs and logs[k].numel() == 1]
+        if present:
+            vals[present] = torch.stack([logs[_LOG_KEYS[i]].detach().float().reshape(()) for i in present])
+            vals[[len(_LOG_KEYS) + i for i in present]] = 1.0
+        if _is_rccl() or not vals.is_cuda:
+            dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+        else:
+            _all_reduce_sum_via_host(vals)
+        n = len(_LOG_KEYS)
+        out = dict(logs)
+        for i, k in enumerate(_LOG_KEYS):
+            if k in logs:
+                out[k] = vals[i] / vals[n + i].clamp(min=1.0)
+        return out
 
     def step(self, data) -> Dict[str, torch.Tensor]:
-        sync = self._sync if self.distributed else None
+        sync = _DataParallelSync(self) if self.distributed else None
         if self.edge_capacity is None:
-            return self.model.training_step(data, self.opt_g, self.opt_d, sync)
+            logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
+            return self.reduce_logs(logs) if (self.distributed and self.sync_logs) else logs
         data["edge_capacity"] = self.edge_capacity
         logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
+        if self.distributed and self.sync_logs:
+            logs = self.reduce_logs(logs)
         if self._overflows is None:
             self._overflows = torch.zeros((), dtype=torch.int64, device=data["edge_plan"].overflow.device)
         self._overflows.add_(data["edge_plan"].overflow)  # in place: a recorded step keeps counting when replayed

@@ -107,3 +107,23 @@ def test_sharded_batches_cover_every_scene(tmp_path):
     per_rank = [[int(b.num_nodes) for b in ds.batches(data, 1, shuffle=True, seed=1, rank=r, world_size=2)] for r in (0, 1)]
     assert len(per_rank[0]) == len(per_rank[1]) == 4
     assert set(per_rank[0]) | set(per_rank[1]) == set(sizes)
+
+
+def test_out_of_range_indices_are_refused():
+    """An index that addresses no agent / lane must raise on the host (the device kernels index unchecked)."""
+    import pytest
+    from hivt_gan_amd.dataset import sanitize
+    scene = hv.make_scene(2)
+    bad = scene.clone()
+    bad["edge_index"][0, 0] = int(scene.num_nodes)
+    with pytest.raises(ValueError, match="edge_index entries"):
+        sanitize(bad)
+    bad = scene.clone()
+    bad["lane_actor_index"][0, 0] = int(scene["lane_vectors"].shape[0])
+    with pytest.raises(ValueError, match="lane ids"):
+        sanitize(bad)
+    bad = scene.clone()
+    bad["lane_actor_index"][1, 0] = -1
+    with pytest.raises(ValueError, match="actor ids"):
+        sanitize(bad)
+    sanitize(scene.clone())

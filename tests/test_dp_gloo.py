@@ -56,30 +56,45 @@ def free_port():
         return s.getsockname()[1]
 
 
-def worker(rank, world, port, poison_rank, out_dir):
+def worker(rank, world, port, poison_rank, out_dir, critic_steps=1, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)
         model = make_model()
+        model.critic_steps = critic_steps
         if rank == 1:  # construction-time broadcast must make this irrelevant
             with torch.no_grad():
                 for p in model.parameters():
                     p.add_(0.123)
-        trainer = hv.GanTrainer(model)
+        trainer = hv.GanTrainer(model, overlap=overlap)
         assert trainer.distributed and set(trainer.buckets) == {"generator", "critic"}
+        assert len(trainer.buckets["generator"].chunks) == 4  # agent-agent, temporal + lane, interaction, decoder
         reduced = {}
+        calls = []
         plain_sync = trainer._sync
 
         def recording_sync(group, bad=None):
-            plain_sync(group, bad)
-            reduced[group] = trainer.buckets[group].flat.clone()
+            share = plain_sync(group, bad)
+            bucket = trainer.buckets[group]
+            reduced[group] = bucket.flat[:bucket.total].clone()
+            calls.append(group)
+            return share
         trainer._sync = recording_sync
         batch = hv.make_batch(2, first_index=10 * rank)
         if rank == poison_rank:
             batch["y"][0, 0, 0] = float("nan")
         logs = trainer.step(batch)
-        assert ("skipped" in logs) == (rank == poison_rank)
+        assert calls == ["critic"] * critic_steps + ["generator"], calls
+        # the logs are averaged over the ranks that produced them, in one collective
+        if poison_rank < 0:
+            both = [None, None]
+            dist.all_gather_object(both, float(logs["reg_loss"]))
+            assert both[0] == both[1]
+        elif rank == poison_rank:  # averaged over the ranks that produced the entry: this one alone
+            assert float(logs["skipped"]) == 1.0 and "reg_loss" not in logs
+        else:
+            assert "skipped" not in logs and bool(torch.isfinite(logs["reg_loss"]))
         state = torch.cat([p.detach().flatten() for p in model.parameters()])
         gathered = [torch.empty_like(state) for _ in range(world)]
         dist.all_gather(gathered, state)
@@ -123,10 +138,12 @@ def single_process_reference(poison_rank):
                               for i in range(len(captured[group][0]))]) for group in captured}
 
 
-@pytest.mark.parametrize("poison_rank", [-1, 1])
-def test_two_rank_step_matches_manual_average(tmp_path, poison_rank):
+@pytest.mark.parametrize("poison_rank,overlap", [(-1, False), (1, False), (-1, True), (1, True)])
+def test_two_rank_step_matches_manual_average(tmp_path, poison_rank, overlap):
+    """``overlap``: every chunk of a bucket is reduced from a gradient hook during the backward pass
+    (asynchronous collectives) instead of all at once after it; the reduced values must be the same."""
     port = free_port()
-    mp.spawn(worker, args=(2, port, poison_rank, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, port, poison_rank, str(tmp_path), 1, overlap), nprocs=2, join=True)
     dp = torch.load(os.path.join(str(tmp_path), "dp_grads.pt"))
     ref = single_process_reference(poison_rank)
     for group in ("critic", "generator"):
@@ -136,6 +153,13 @@ def test_two_rank_step_matches_manual_average(tmp_path, poison_rank):
         # one), so agreement is judged against the scale of the gradient vector
         err = float((dp[group] - ref[group]).abs().max())
         assert err <= 1e-6 * float(ref[group].abs().max()), f"{group} gradients differ by {err:.3e}"
+
+
+def test_two_critic_steps_with_a_poisoned_rank_stay_in_lock_step(tmp_path):
+    """critic_steps = 2: the rank that discards its batch must enter two critic reductions and one
+    generator reduction like the healthy rank (the worker asserts the sequence and identical replicas)."""
+    port = free_port()
+    mp.spawn(worker, args=(2, port, 1, str(tmp_path), 2, False), nprocs=2, join=True)
 
 
 def test_flat_bucket_packs_and_hands_back_views():

@@ -17,3 +17,16 @@ def test_two_ranks_share_one_gpu():
     done = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_rehearsal.py")], cwd=ROOT,
                           capture_output=True, text=True, timeout=170)
     assert done.returncode == 0 and "dp rehearsal OK" in done.stdout, done.stdout[-2000:] + done.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_when_two_gpus_are_present():
+    """The same rehearsal over RCCL, one GPU per rank, with the chunked all-reduces overlapping the backward
+    pass: needs two visible GPUs, skipped otherwise."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HIVT_REHEARSAL_BACKEND="nccl")
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_rehearsal.py")], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=170)
+    assert done.returncode == 0 and "dp rehearsal OK" in done.stdout, done.stdout[-2000:] + done.stderr[-4000:]

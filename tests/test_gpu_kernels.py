@@ -903,3 +903,20 @@ def test_linear_dropout_and_blocks_large_grids():
     _close_scale(got[0], agg.grad, 1e-4, "update tail d_agg")
     _close_scale(got[1], c.grad, 1e-4, "update tail d_center")
     assert torch.equal(gy, gy_before) and torch.equal(r.grad, 2 * gy)
+
+
+def test_unsupported_gpu_shapes_raise_instead_of_falling_back():
+    """No quiet hand-over to the framework's operators for GPU tensors outside the built shapes."""
+    x = torch.randn(10, 256, device=DEV)
+    norm = torch.nn.LayerNorm(256).to(DEV)
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    with pytest.raises(ops.UnsupportedShapeError):
+        ops.layer_norm(x, norm)
+    with pytest.raises(ops.UnsupportedShapeError):
+        ops.layer_norm_residual(x, norm)
+    with pytest.raises(ops.UnsupportedShapeError):
+        ops.fused_linear(x, lin.weight, lin.bias, layer_norm=norm)
+    layer = hv.TemporalEncoderLayer(embed_dim=64, num_heads=8, dropout=0.0).to(DEV)
+    with pytest.raises(ops.UnsupportedShapeError):
+        layer._sa_block(torch.randn(40, 3, 64, device=DEV), torch.randn(40, 3, 64, device=DEV))
+    assert ops.fused_linear(x, lin.weight, lin.bias).shape == (10, 256)  # the plain product has no width limit

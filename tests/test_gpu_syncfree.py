@@ -154,9 +154,9 @@ def test_edge_capacity_overflow_discards_the_batch():
 
 def test_bucketed_all_reduce_path_on_gpu_single_rank():
     """The data-parallel path (flat buckets, RCCL all-reduce, device-side zeroing of a discarded batch)
-    with a world of one rank must reproduce the plain step; a poisoned batch must leave the model
-    untouched... except through the averaged (all-zero) gradient, which AdamW turns into pure weight
-    decay on the generator -- so that case is checked on the reduced buffers instead."""
+    with a world of one rank must reproduce the plain step; a batch that every rank discards must leave
+    the model untouched, as in the single-process step: the share of contributing ranks travels in the
+    bucket and a share of zero skips the update."""
     import torch.distributed as dist
     import socket
     with socket.socket() as s:
@@ -183,8 +183,15 @@ def test_bucketed_all_reduce_path_on_gpu_single_rank():
                 assert float((pa[k] - pb[k]).detach().abs().max()) < 2e-4, k
         poisoned = batches[0].clone()
         poisoned["y"][0, 0, 0] = float("nan")
+        before = {k: v.clone() for k, v in dp_model.state_dict().items()}
+        opt_before = [st["exp_avg"].clone() for st in list(dp.opt_g.state.values())[:3]]
         logs = dp.step(poisoned)
         assert float(logs["skipped"]) == 1.0
+        for k, v in dp_model.state_dict().items():
+            if not (k.endswith("_u") or k.endswith("_v")):  # the critics' power iteration still ran
+                assert torch.equal(v, before[k]), k
+        for a, st in zip(opt_before, list(dp.opt_g.state.values())[:3]):
+            assert torch.equal(a, st["exp_avg"])
         for group in ("critic", "generator"):
             flat = dp.buckets[group].flat
             assert bool(torch.isfinite(flat).all()) and float(flat.abs().max()) == 0.0, group

@@ -101,3 +101,36 @@ def test_metric_states_add_up_across_two_ranks(tmp_path):
     assert torch.allclose(got["val_minMR"], mr.compute())
     assert torch.allclose(got["val_endpoint_diversity"], div.compute())
     assert math.isnan(float(got["val_jerk"]))  # never updated
+
+
+def _metrics_worker(rank, world, port):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hivt_gan_amd.metrics import ValidationMetrics
+        m = ValidationMetrics()
+        if rank == 0:  # the other rank has seen no validation batch at all
+            gen = torch.Generator().manual_seed(0)
+            pred, target = torch.randn(5, 30, 2, generator=gen), torch.randn(5, 30, 2, generator=gen)
+            m.minADE.update(pred, target)
+            m.minFDE.update(pred, target)
+            m.jerk.update(pred[:, :3])  # ignored: fewer than four steps
+        m.sync()
+        out = m.compute()
+        vals = [None, None]
+        dist.all_gather_object(vals, {k: float(v) for k, v in out.items()})
+        assert vals[0]["val_minADE"] == vals[1]["val_minADE"] and vals[0]["val_minADE"] == vals[0]["val_minADE"]
+        assert vals[0]["val_jerk"] != vals[0]["val_jerk"]  # NaN: no rank has a sample
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_with_a_rank_that_saw_nothing_stays_in_lock_step():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_metrics_worker, args=(2, port), nprocs=2, join=True)

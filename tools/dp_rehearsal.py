@@ -29,10 +29,15 @@ def worker(rank, world, port, steps):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import hivt_gan_amd as hv
     from bench import model_config
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    say("group up")
-    dev = torch.device("cuda", 0)
+    backend = os.environ.get("HIVT_REHEARSAL_BACKEND", "gloo")
+    # RCCL wants a device per rank; over gloo the ranks share cuda:0
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    say("group up", backend)
     torch.manual_seed(2022)
     cfg = model_config(64)
     cfg["dropout"] = 0.0
@@ -55,27 +60,30 @@ def worker(rank, world, port, steps):
     plain_sync = trainer._sync
 
     def recording_sync(group, bad=None):
+        bucket = trainer.buckets[group]
         if group not in local:
-            local[group] = trainer.buckets[group].pack().clone()
-        plain_sync(group, bad)
-        local.setdefault(group + "_reduced", trainer.buckets[group].flat.clone())
+            local[group] = bucket.pack().clone()
+        share = plain_sync(group, bad)
+        local.setdefault(group + "_reduced", bucket.flat[:bucket.total].clone())
+        return share
     trainer._sync = recording_sync
 
     for i in range(steps):
         logs = run_step(i)
         torch.cuda.synchronize()
         say("step", i, {k: round(float(v), 5) for k, v in logs.items() if v.numel() == 1})
-        state = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+        state = torch.cat([p.detach().flatten() for p in model.parameters()])
+        state = state if backend == "nccl" else state.cpu()
         both = [torch.empty_like(state) for _ in range(world)]
         dist.all_gather(both, state)
         assert torch.equal(both[0], both[1]), f"ranks diverged after step {i}"
         assert all(bool(torch.isfinite(v).all()) for v in logs.values())
         if i == 0:
             for group in ("critic", "generator"):
-                mine = local[group].cpu()
+                mine = local[group] if backend == "nccl" else local[group].cpu()
                 parts = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(parts, mine)
-                mean = (parts[0] + parts[1]) / 2
+                mean = ((parts[0] + parts[1]) / 2).cpu()
                 err = float((local[group + "_reduced"].cpu() - mean).abs().max())
                 scale = float(mean.abs().max())
                 say(group, "reduced vs mean of locals: err", err, "scale", scale)
