@@ -10,16 +10,18 @@ import re
 import sys
 
 src, tag, embed_dim, scenes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-CALLER = {("1", "false", "true"): "AAEncoder", ("4", "false", "false"): "ALEncoder",
-          ("1", "true", "false"): "GlobalInteractorLayer"}
+def caller(glob, split):
+    """Which module launches a kernel instance: node terms -> interaction module, one row per lane slot ->
+    agent-agent stage (1.3 edges per row), otherwise the lane-actor stage."""
+    return "GlobalInteractorLayer" if glob == "true" else ("AAEncoder" if split == "true" else "ALEncoder")
 out = {}
 for name, scale in (("pmc_fetch_size.csv", 2 * 1024.0), ("pmc_write_size.csv", 1024.0)):
     for r in csv.DictReader(open(f"{src}/{name}")):
-        m = re.search(r"seg_attn_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (\w+), (\w+)>", r["kernel"])
+        m = re.search(r"seg_attn_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?>", r["kernel"])
         if not m:
             continue
-        kind, _d, _lph, wpn, glob, split = m.groups()
-        key = f"{kind}/{CALLER[(wpn, glob, split)]}"
+        kind, _d, _lph, _wpn, glob, split, _unroll = m.groups()
+        key = f"{kind}/{caller(glob, split)}"
         e = out.setdefault(key, {"read_bytes": 0.0, "write_bytes": 0.0})
         e["read_bytes" if "fetch" in name else "write_bytes"] += float(r["mean_per_dispatch"]) * scale
 for e in out.values():
