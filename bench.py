@@ -246,13 +246,31 @@ def main():
 
     # launch schedule chosen by measurement (untimed set-up, like the capacity calibration above)
     tuned = trainer.tune(eager_step) if not args.no_tune else {}
-    graphed = None
-    if world == 1 and spec is not None and not args.no_graph:
+    graphed, graph_note = None, None
+    if spec is not None and not args.no_graph:
         # the whole step recorded once and replayed: batches padded to one fixed shape (inert padding), each
         # step copies its batch into the recording's input tensors (device to device) and launches the graph
+        # (data parallel: a few graph segments with the gradient all-reduces between them)
         from hivt_gan_amd.graph import GraphedStep
+        if world > 1:  # every rank pads to the same shapes: the largest capacities of any rank
+            caps = torch.tensor([spec.num_nodes, spec.num_lanes, spec.num_edges, spec.num_lane_actor, *spec.edge_capacity],
+                                dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+            c = [int(v) for v in caps.tolist()]
+            spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:7]))
+            trainer.edge_capacity = spec.edge_capacity
         padded = [hv.pad_batch(b, spec) for b, _ in pool]
-        graphed = GraphedStep(trainer, spec, padded[0], critic_streams=bool(tuned.get("critic_streams", False)))
+        try:
+            graphed = GraphedStep(trainer, spec, padded[0], critic_streams=bool(tuned.get("critic_streams", False)))
+        except Exception as exc:  # noqa: BLE001 -- the eager step is always available
+            graph_note = f"recording failed ({type(exc).__name__}: {exc}); launching eagerly"
+            if rank == 0:
+                print("warning: " + graph_note, file=sys.stderr)
+        if world > 1:  # all ranks replay or none does
+            ok = torch.tensor([1 if graphed is not None else 0], device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graphed = None
 
     def run_step(i: int):
         if graphed is not None:
@@ -344,9 +362,11 @@ def main():
                                    + ("bf16 dense products" if args.matmul == "bf16" else "fp32"),
                        "scenes_per_gpu": args.scenes, "embed_dim": args.embed_dim, "parallelism": f"dp{world}",
                        "guards": "host" if args.host_guards else "device",
-                       "launch": ("one recorded HIP graph per step (%d kernel + %d copy nodes), inputs copied into its "
-                                  "static tensors" % (graphed.nodes.get("kernel", 0), graphed.nodes.get("memcpy", 0)))
-                       if graphed is not None else "eager",
+                       "launch": ("recorded HIP graph, %d segment(s) per step (%d kernel + %d copy nodes), inputs copied "
+                                  "into its static tensors" % (sum(1 for k, _ in graphed.segments if k == "graph"),
+                                                               graphed.nodes.get("kernel", 0),
+                                                               graphed.nodes.get("memcpy", 0)))
+                       if graphed is not None else (graph_note or "eager"),
                        "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
                        if graphed is not None else "kernel time stamps inside the timed region",
                        "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,

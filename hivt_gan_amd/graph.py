@@ -8,6 +8,10 @@ launches plain kernels only (no runtime memset / memcpy, no allocation), the opt
 counter and the skip flag from device memory, and every dropout site adds a device-side seed to its
 per-call constant, which the recorded step advances by itself.
 
+A data-parallel step is recorded in segments: the gradient all-reduces run eagerly between them (the
+payloads are 1.5 MB and 10 MB, a fraction of a millisecond on xGMI, so what matters for scaling is that
+the ranks stay GPU-bound, not that the collectives hide behind the backward pass).
+
 What a recorded step fixes until it is recorded again: the learning rate (``GanTrainer.end_epoch``
 invalidates the recording), the critic-stream schedule, the batch shapes (``BatchSpec``).
 """
@@ -54,19 +58,38 @@ def node_census(graph: "torch.cuda.CUDAGraph") -> Dict[str, int]:
     return dict(kinds)
 
 
+class _RecordedSync:
+    """Gradient reduction of a recorded data-parallel step: packing (and zeroing a discarded rank's share)
+    is recorded, the collectives run eagerly BETWEEN two graph segments, the hand-back of the averaged
+    gradients is host-side bookkeeping."""
+
+    def __init__(self, owner: "GraphedStep") -> None:
+        self.owner = owner
+
+    def begin(self, group: str, bad: Optional[torch.Tensor] = None) -> None:
+        self.owner.trainer.buckets[group].begin(bad)
+
+    def __call__(self, group: str, bad: Optional[torch.Tensor] = None):
+        bucket = self.owner.trainer.buckets[group]
+        bucket.pack(bad)
+        self.owner._break(bucket.reduce_packed)
+        bucket._armed = False
+        bucket.unpack()
+        return bucket.flat[bucket.total]
+
+
 class GraphedStep:
-    """``trainer.step`` on fixed-shape batches as one graph launch.
+    """``trainer.step`` on fixed-shape batches as one graph launch (single process) or as a few graph
+    segments with the gradient all-reduces between them (data parallel).
 
     ``example`` is a batch already padded to ``spec`` and resident on the GPU; its tensors become the
-    static inputs of the recording.  ``run(batch)`` copies another padded batch into them (thirteen
+    static inputs of the recording.  ``run(batch)`` copies another padded batch into them (a dozen
     device-to-device copies) and replays; ``run()`` replays on whatever the static inputs hold."""
 
     def __init__(self, trainer, spec: BatchSpec, example: TemporalData, warmup: int = 3,
                  critic_streams: bool = False) -> None:
         if trainer.edge_capacity is None:
             raise RuntimeError("a recorded step needs the read-back-free mode (GanTrainer(edge_capacity=...))")
-        if trainer.distributed:
-            raise RuntimeError("the recorded step covers the single-process step; data-parallel runs launch eagerly")
         self.trainer = trainer
         self.spec = spec
         self.static = TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
@@ -78,24 +101,57 @@ class GraphedStep:
         self.critic_streams = bool(critic_streams)
         self.warmup = int(warmup)
         self.nodes: Dict[str, int] = {}
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.segments: list = []  # ("graph", CUDAGraph) / ("call", function) in replay order
         self.logs: Dict[str, torch.Tensor] = {}
         self._stream = torch.cuda.Stream(device=dev)
+        self._capturing = False
+        self._pool = None
+        self._sync = _RecordedSync(self) if trainer.distributed else None
+        if trainer.distributed:
+            for bucket in trainer.buckets.values():
+                bucket.overlap = False  # the reductions of a recorded step sit between its segments
+        self.sync_logs = bool(trainer.distributed and trainer.sync_logs)
         self.replays = 0
         self.record()
 
+    @property
+    def graph(self):
+        """The recording of a single-process step (one segment)."""
+        graphs = [g for kind, g in self.segments if kind == "graph"]
+        return graphs[0] if len(graphs) == 1 else None
+
     # ------------------------------------------------------------------------------------------
     def _one_step(self) -> Dict[str, torch.Tensor]:
-        prev_seed, prev_calls, prev_conc = ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS
+        t = self.trainer
+        prev = (ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS, t._sync_override, t.sync_logs)
         ops.DEVICE_SEED, ops._seed_calls = self.seed, 0
         losses.CONCURRENT_CRITICS = self.critic_streams
+        t._sync_override, t.sync_logs = self._sync, False
         try:
             self.seed.add_(_SEED_STRIDE)
             self.static["y"] = self._y       # forward rebinds the entry to the rotated targets
             self.static["edge_plan"] = None  # edge construction belongs to the step
-            return self.trainer.step(self.static)
+            return t.step(self.static)
         finally:
-            ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS = prev_seed, prev_calls, prev_conc
+            ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS, t._sync_override, t.sync_logs = prev
+
+    def _begin_segment(self) -> None:
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        g.capture_begin(pool=self._pool, capture_error_mode="global")
+        self.segments.append(("graph", g))
+
+    def _end_segment(self) -> None:
+        self.segments[-1][1].capture_end()
+
+    def _break(self, fn) -> None:
+        """``fn`` must run outside any recording (a collective): eagerly right away, or, while recording,
+        between the segment that ends here and the one that starts here."""
+        if not self._capturing:
+            fn()
+            return
+        self._end_segment()
+        self.segments.append(("call", fn))
+        self._begin_segment()
 
     def record(self) -> None:
         """(Re)records the step: ``warmup`` eager steps on the recording stream (allocator, optimizer
@@ -107,19 +163,34 @@ class GraphedStep:
                 self._one_step()
         current.wait_stream(self._stream)
         torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(self.graph, stream=self._stream):
-            self.logs = self._one_step()
+        self.segments = []
+        self._pool = torch.cuda.graph_pool_handle()
+        import gc
+        gc.collect()
+        with torch.cuda.stream(self._stream):
+            self._begin_segment()
+            self._capturing = True
+            try:
+                self.logs = self._one_step()
+            finally:
+                self._capturing = False
+                self._end_segment()
         # A runtime memset recorded as a graph node takes no effect when the graph is replayed on this stack
         # (torch 2.10 / ROCm 7.2): a multi-block framework reduction, which clears its semaphores that way,
         # returns wrong sums from the second replay on.  The step is written to issue none; refuse to replay
         # a recording that holds one rather than train on wrong numbers.
-        self.nodes = node_census(self.graph)
+        self.nodes = {}
+        for kind, g in self.segments:
+            if kind == "graph":
+                for k, v in node_census(g).items():
+                    self.nodes[k] = self.nodes.get(k, 0) + v
         if self.nodes.get("memset", 0):
-            self.graph = None
+            self.segments = []
             raise RuntimeError(f"the recorded step holds {self.nodes['memset']} runtime memset node(s) {self.nodes}; "
                                "tools/find_memsets.py names the operators that issue them")
-        self.graph.instantiate()
+        for kind, g in self.segments:
+            if kind == "graph":
+                g.instantiate()
         self._lr = [g["lr"] for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None
                     for g in opt.param_groups]
 
@@ -142,9 +213,13 @@ class GraphedStep:
             self.record()
         if batch is not None:
             self.load(batch)
-        self.graph.replay()
+        for kind, item in self.segments:
+            if kind == "graph":
+                item.replay()
+            else:
+                item()
         self.replays += 1
-        return self.logs
+        return self.trainer.reduce_logs(self.logs) if self.sync_logs else self.logs
 
 
 def padded_pool(batches, spec: BatchSpec):

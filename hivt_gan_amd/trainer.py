@@ -40,11 +40,16 @@ def _all_reduce_sum_via_host(t: torch.Tensor, group=None) -> None:
     t.copy_(host)
 
 
+# every gradient of a flat bucket starts at a multiple of this many elements
+_ALIGN = 32
+
+
 class FlatGradBucket:
     """Gradients of a parameter group in one contiguous buffer, reduced in a few chunks.
 
-    The buffer holds the group's gradients in parameter order plus one trailing element, the share of
-    ranks that contributed (1 - bad, averaged).  ``chunks`` partitions the parameters in the order their
+    The buffer holds the group's gradients in parameter order, every gradient starting at a multiple of
+    128 bytes (the views handed back to the optimizer take its vectorised path; the gaps stay zero), plus
+    one trailing element, the share of ranks that contributed (1 - bad, averaged).  ``chunks`` partitions the parameters in the order their
     gradients become ready during backward (decoder first, agent-agent encoder last).  With ``overlap``
     every chunk is packed and handed to an asynchronous all-reduce from a post-accumulate hook as soon
     as its last gradient has arrived, so the collective runs beside the rest of the backward pass;
@@ -55,14 +60,16 @@ class FlatGradBucket:
                  overlap: bool = False, group=None) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.sizes = [p.numel() for p in self.params]
-        self.total = sum(self.sizes)
         self.group = group
         self.overlap = bool(overlap)
         self.flat: Optional[torch.Tensor] = None
+        self._views: List[torch.Tensor] = []
         offsets, off = {}, 0
         for p, n in zip(self.params, self.sizes):
             offsets[id(p)] = off
-            off += n
+            off += -(-n // _ALIGN) * _ALIGN
+        self.offsets = [offsets[id(p)] for p in self.params]
+        self.total = off  # elements of the gradient part (alignment gaps included)
         if chunks is None:
             chunks = [self.params]
         own = {id(p) for p in self.params}
@@ -72,9 +79,10 @@ class FlatGradBucket:
         if flat_order != [id(p) for p in self.params]:
             raise ValueError("chunks must list the group's parameters in the group's order")
         self.chunks = []  # (first element, one past the last, parameters)
-        for c in chunks:
-            a = offsets[id(c[0])]
-            self.chunks.append((a, a + sum(p.numel() for p in c), c))
+        starts = [offsets[id(c[0])] for c in chunks] + [self.total]
+        for c, a, b in zip(chunks, starts[:-1], starts[1:]):
+            self.chunks.append((a, b, c))
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         self._chunk_of = {id(p): i for i, (_, _, c) in enumerate(self.chunks) for p in c}
         self._pending: List[int] = []
         self._packed: List[bool] = []
@@ -91,6 +99,7 @@ class FlatGradBucket:
     def _buffer(self) -> torch.Tensor:
         if self.flat is None or self.flat.device != self.params[0].device:
             self.flat = torch.zeros(self.total + 1, dtype=self.params[0].dtype, device=self.params[0].device)
+            self._views = [self.flat[o:o + n].view_as(p) for p, o, n in zip(self.params, self.offsets, self.sizes)]
         return self.flat
 
     def begin(self, bad: Optional[torch.Tensor] = None) -> None:
@@ -106,7 +115,7 @@ class FlatGradBucket:
         self._armed = True
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
-        if not self._armed:
+        if not (self._armed and self.overlap):
             return
         self._pending[self._chunk_of[id(p)]] -= 1
         self._launch_ready(force=False)
@@ -126,25 +135,17 @@ class FlatGradBucket:
     def _pack_chunk(self, i: int) -> None:
         a, b, params = self.chunks[i]
         piece = self.flat[a:b]
-        base, item = self.flat.data_ptr(), self.flat.element_size()
-        offs, off = [], a
-        for p in params:
-            offs.append(off)
-            off += p.numel()
+        views = [self._views[self._index[id(p)]] for p in params]
         # a gradient that is still the view handed back by the last unpack (zeroed in place, never replaced:
         # a rank that discarded its batch) already sits where it belongs
-        in_place = [p.grad is not None and p.grad.data_ptr() == base + o * item for p, o in zip(params, offs)]
-        if not any(in_place) and all(p.grad is not None for p in params):
-            torch.cat([p.grad.reshape(-1) for p in params], out=piece)
-        else:
-            for p, o, same in zip(params, offs, in_place):
-                if same:
-                    continue
-                n = p.numel()
-                if p.grad is None:
-                    self.flat[o:o + n].zero_()
-                else:
-                    self.flat[o:o + n].copy_(p.grad.reshape(-1))
+        todo = [(v, p.grad) for v, p in zip(views, params)
+                if not (p.grad is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape)]
+        missing = [v for v, g in todo if g is None]
+        todo = [(v, g) for v, g in todo if g is not None]
+        if todo:  # one multi-tensor copy
+            torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
+        if missing:
+            torch._foreach_zero_(missing)
         if self._bad is not None:
             piece.masked_fill_(self._bad, 0.0)
         if i == len(self.chunks) - 1:  # the contribution flag travels with the last chunk
@@ -185,11 +186,14 @@ class FlatGradBucket:
                 self._pack_chunk(i)
         return self.flat[:self.total]
 
+    def gradients(self) -> torch.Tensor:
+        """The buffer's gradients without the alignment gaps, concatenated in parameter order (a copy)."""
+        self._buffer()
+        return torch.cat([v.reshape(-1) for v in self._views])
+
     def unpack(self) -> None:
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, v in zip(self.params, self._views):
+            p.grad = v
 
     def finish(self, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
         """After the backward pass: reduces whatever has not been handed to a collective yet, waits for all
@@ -211,6 +215,13 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None, bad: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.finish(bad)
+
+    def reduce_packed(self) -> None:
+        """The collectives alone, on a buffer that ``pack`` has filled: every chunk in the canonical order,
+        blocking.  A recorded step calls this between two of its graph segments (the packing before it and
+        the update after it are recorded, the collectives are not)."""
+        for i in range(len(self.chunks) - 1, -1, -1):
+            self._reduce(i, async_op=False)
 
 
 class _DataParallelSync:
@@ -276,6 +287,7 @@ class GanTrainer:
             if model.use_gan:
                 self.buckets["critic"] = FlatGradBucket(model.critic_parameters(), overlap=overlap)
         self._overflows: Optional[torch.Tensor] = None
+        self._sync_override = None  # a recorded step installs its own reducer here (hivt_gan_amd/graph.py)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -328,7 +340,7 @@ class GanTrainer:
         return out
 
     def step(self, data) -> Dict[str, torch.Tensor]:
-        sync = _DataParallelSync(self) if self.distributed else None
+        sync = (self._sync_override or _DataParallelSync(self)) if self.distributed else None
         if self.edge_capacity is None:
             logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
             return self.reduce_logs(logs) if (self.distributed and self.sync_logs) else logs

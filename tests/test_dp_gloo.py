@@ -77,7 +77,7 @@ def worker(rank, world, port, poison_rank, out_dir, critic_steps=1, overlap=Fals
         def recording_sync(group, bad=None):
             share = plain_sync(group, bad)
             bucket = trainer.buckets[group]
-            reduced[group] = bucket.flat[:bucket.total].clone()
+            reduced[group] = bucket.gradients()
             calls.append(group)
             return share
         trainer._sync = recording_sync
@@ -169,8 +169,9 @@ def test_flat_bucket_packs_and_hands_back_views():
     bucket = FlatGradBucket(list(lin.parameters()) + [extra])
     lin(torch.ones(4, 3)).sum().backward()
     flat = bucket.pack()
-    assert flat.shape == (6 + 2 + 5,)
-    assert torch.equal(flat[:6].view(2, 3), torch.full((2, 3), 4.0)) and torch.all(flat[8:] == 0)
+    assert bucket.offsets == [0, 32, 64] and flat.shape == (96,)  # every gradient on a 128-byte boundary
+    assert torch.equal(flat[:6].view(2, 3), torch.full((2, 3), 4.0)) and torch.all(flat[6:32] == 0)
+    assert torch.all(flat[32:34] == 4.0) and torch.all(flat[34:] == 0)
     flat.mul_(0.5)
     bucket.unpack()
     assert lin.weight.grad.data_ptr() == flat.data_ptr()

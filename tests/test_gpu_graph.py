@@ -95,3 +95,45 @@ def test_every_replay_draws_new_dropout_masks():
     same = [float(step0.run(padded[0])["reg_loss"]) for _ in range(3)]
     assert len(set(same)) == 1, same
     assert ops.DEVICE_SEED is None  # the recording hands the seed scalar back
+
+
+def test_recorded_data_parallel_step_in_segments_world_of_one():
+    """The data-parallel step recorded as graph segments with the all-reduces between them (RCCL, a world of
+    one rank): same parameters as the single-process recording after the same steps, and a step that the
+    only rank discards leaves the model untouched."""
+    import socket
+    import torch.distributed as dist
+    order = [0, 1, 0]
+    ref_model = make(0.0)
+    padded, spec = batches_and_spec(ref_model, count=2)
+    ref_tr = hv.GanTrainer(ref_model, distributed=False, edge_capacity=spec.edge_capacity)
+    ref_step = GraphedStep(ref_tr, spec, padded[0])
+    for i in order:
+        ref_step.run(padded[i])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=DEV)
+    try:
+        model = make(0.0)
+        tr = hv.GanTrainer(model, distributed=True, edge_capacity=spec.edge_capacity)
+        step = GraphedStep(tr, spec, padded[0])
+        kinds = [k for k, _ in step.segments]
+        assert kinds == ["graph", "call", "graph", "call", "graph"], kinds  # critic reduction, generator reduction
+        assert step.nodes.get("memset", 0) == 0
+        for i in order:
+            logs = step.run(padded[i])
+        torch.cuda.synchronize()
+        assert float(logs["skipped"]) == 0.0
+        for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
+            assert torch.equal(a, b), f"{k}: segmented data-parallel recording differs from the single-process one"
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        poisoned = padded[0].clone()
+        poisoned["y"][1, 0, 0] = float("nan")
+        logs = step.run(poisoned)
+        assert float(logs["skipped"]) == 1.0
+        for k, v in model.state_dict().items():
+            if not (k.endswith("_u") or k.endswith("_v")):
+                assert torch.equal(v, before[k]), k
+    finally:
+        dist.destroy_process_group()

@@ -62,9 +62,10 @@ def worker(rank, world, port, steps):
     def recording_sync(group, bad=None):
         bucket = trainer.buckets[group]
         if group not in local:
-            local[group] = bucket.pack().clone()
+            bucket.pack()
+            local[group] = bucket.gradients()
         share = plain_sync(group, bad)
-        local.setdefault(group + "_reduced", bucket.flat[:bucket.total].clone())
+        local.setdefault(group + "_reduced", bucket.gradients())
         return share
     trainer._sync = recording_sync
 
@@ -94,6 +95,30 @@ def worker(rank, world, port, steps):
     for i in range(3):
         run_step(steps + i)
     torch.cuda.synchronize()
+    # the same step recorded in graph segments with the reductions between them
+    from hivt_gan_amd.graph import GraphedStep
+    spec = hv.GanTrainer.calibrate(model, pool)
+    caps = torch.tensor([spec.num_nodes, spec.num_lanes, spec.num_edges, spec.num_lane_actor, *spec.edge_capacity])
+    caps = caps.to(dev) if backend == "nccl" else caps
+    dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+    c = [int(v) for v in caps.tolist()]
+    spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:7]))
+    trainer.edge_capacity = spec.edge_capacity
+    for b, y in zip(pool, ys):
+        b["y"] = y
+    padded = [hv.pad_batch(b, spec) for b in pool]
+    recorded = GraphedStep(trainer, spec, padded[0])
+    say("recorded", [k for k, _ in recorded.segments], recorded.nodes)
+    for i in range(3):
+        logs = recorded.run(padded[i % len(padded)])
+        torch.cuda.synchronize()
+        state = torch.cat([p.detach().flatten() for p in model.parameters()])
+        state = state if backend == "nccl" else state.cpu()
+        both = [torch.empty_like(state) for _ in range(world)]
+        dist.all_gather(both, state)
+        assert torch.equal(both[0], both[1]), f"ranks diverged after recorded step {i}"
+        assert all(bool(torch.isfinite(v).all()) for v in logs.values())
+        say("recorded step", i, round(float(logs["g_total"]), 5))
     dist.barrier()
     say("OK")
     faulthandler.cancel_dump_traceback_later()
