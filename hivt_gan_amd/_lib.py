@@ -55,6 +55,8 @@ SIGNATURES = {
                                      c_int64, _P, c_int64, _P]),
     "hivt_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_linear_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_linear_wgrad_group_workspace_bytes": (c_size_t, [_P, c_int32]),
+    "hivt_linear_wgrad_group": (c_int, [_P, c_int32, _P, c_size_t, _P]),
     "hivt_ln_fwd": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int32, _P, c_int64, _P, _P]),
     "hivt_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_ln_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_int64, c_int32, _P, c_int64, _P, c_int64,

@@ -115,45 +115,63 @@ int make_shape(const char* what, int64_t B, int32_t layers, const int32_t* width
   return HIVT_OK;
 }
 
-// scratch: two [B, max_w] activations + the largest weight-gradient workspace + one weight-sized buffer
+// scratch: the backward chains' intermediate rows (dz_1..dz_L of the score chain, e_0..e_L of the penalty
+// chain: all of them are operands of the weight-gradient products issued together at the end) + the workspace
+// of that grouped call
 struct Scratch {
-  float* a;
-  float* b;
-  float* wtmp;
+  float* dz[kMaxHidden + 1];  // dz[l]: [B, w_l], l = 1..L
+  float* e[kMaxHidden + 1];   // e[l]: [B, w_l], l = 0..L
   void* wgrad_ws;
   size_t wgrad_bytes;
 };
 
+size_t act_bytes(const Shape& s, int l) {
+  return align_up((size_t)(s.B > 0 ? s.B : 1) * s.w[l] * sizeof(float), 256);
+}
+
+// upper bound of the grouped call's workspace: every weight takes at most two terms
+size_t group_bytes(const Shape& s) {
+  size_t total = 256;
+  for (int l = 1; l <= s.L; ++l)
+    total += 2 * align_up(hivt_linear_wgrad_workspace_bytes(s.B, s.w[l], s.w[l - 1]), 256);
+  total += align_up(hivt_linear_wgrad_workspace_bytes(s.B, 1, s.w[s.L]), 256);
+  return total;
+}
+
 size_t scratch_bytes(const Shape& s) {
-  size_t act = align_up((size_t)(s.B > 0 ? s.B : 1) * s.max_w * sizeof(float), 256);
-  size_t wg = 0, wt = 0;
-  for (int l = 1; l <= s.L; ++l) {
-    const size_t q = hivt_linear_wgrad_workspace_bytes(s.B, s.w[l], s.w[l - 1]);
-    if (q > wg) wg = q;
-    const size_t t = align_up((size_t)s.w[l] * s.w[l - 1] * sizeof(float), 256);
-    if (t > wt) wt = t;
-  }
-  const size_t q = hivt_linear_wgrad_workspace_bytes(s.B, 1, s.w[s.L]);
-  if (q > wg) wg = q;
-  return 2 * act + wt + wg;
+  size_t total = group_bytes(s);
+  for (int l = 1; l <= s.L; ++l) total += act_bytes(s, l);
+  for (int l = 0; l <= s.L; ++l) total += act_bytes(s, l);
+  return total;
 }
 
 Scratch carve(const Shape& s, void* ws) {
-  Scratch k;
-  const size_t act = align_up((size_t)(s.B > 0 ? s.B : 1) * s.max_w * sizeof(float), 256);
-  size_t wt = 0;
-  for (int l = 1; l <= s.L; ++l) {
-    const size_t t = align_up((size_t)s.w[l] * s.w[l - 1] * sizeof(float), 256);
-    if (t > wt) wt = t;
-  }
+  Scratch k{};
   char* p = reinterpret_cast<char*>(ws);
-  k.a = reinterpret_cast<float*>(p);
-  k.b = reinterpret_cast<float*>(p + act);
-  k.wtmp = reinterpret_cast<float*>(p + 2 * act);
-  k.wgrad_ws = p + 2 * act + wt;
-  k.wgrad_bytes = scratch_bytes(s) - 2 * act - wt;
+  for (int l = 1; l <= s.L; ++l) {
+    k.dz[l] = reinterpret_cast<float*>(p);
+    p += act_bytes(s, l);
+  }
+  for (int l = 0; l <= s.L; ++l) {
+    k.e[l] = reinterpret_cast<float*>(p);
+    p += act_bytes(s, l);
+  }
+  k.wgrad_ws = p;
+  k.wgrad_bytes = group_bytes(s);
   return k;
 }
+
+// one row of the item table of hivt_linear_wgrad_group
+struct Terms {
+  int64_t row[2 * (kMaxHidden + 1)][10];
+  int32_t count = 0;
+  void add(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N, int32_t K, float* dw,
+           float* dbias, bool accumulate, bool joins) {
+    int64_t* r = row[count++];
+    r[0] = (int64_t)(uintptr_t)dy; r[1] = dy_ld; r[2] = (int64_t)(uintptr_t)x; r[3] = x_ld; r[4] = M; r[5] = N; r[6] = K;
+    r[7] = (int64_t)(uintptr_t)dw; r[8] = (int64_t)(uintptr_t)dbias; r[9] = (accumulate ? 1 : 0) | (joins ? 2 : 0);
+  }
+};
 
 #define HIVT_TRY(expr)            \
   do {                            \
@@ -346,38 +364,24 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
   const Scratch k = carve(s, workspace);
   const float keep_scale = 1.0f / (1.0f - dropout_p);
 
-  if (g_scores != nullptr) {
+  // The weight gradients of both chains are leaves: their products are collected here and issued in one
+  // grouped call at the end, each weight as one entry (score-chain term, joined by the penalty-chain term).
+  const bool scores_chain = g_scores != nullptr, penalty_chain = g_norm2 != nullptr;
+  if (scores_chain) {
     // ---- gradient of the scores: ordinary backward through the layers ----
-    // output layer: dw_o = g^T h_L, db_o = sum g
-    if (params)
-      HIVT_TRY(hivt_linear_wgrad(g_scores, 1, saved + s.h_off[layers], s.w[layers], B, 1, s.w[layers], dw[layers],
-                                 dbias[layers], k.wgrad_ws, k.wgrad_bytes, stream));
     // dz_L = (g w_o) * c_L
-    float* dz = k.a;
-    float* other = k.b;
     hipLaunchKernelGGL(masked_product_kernel, dim3(blocks_for(B * s.w[layers])), dim3(256), 0, st, (const float*)nullptr,
-                       g_scores, w[layers], saved + s.h_off[layers], keep_scale, neg_slope, B, s.w[layers], dz);
+                       g_scores, w[layers], saved + s.h_off[layers], keep_scale, neg_slope, B, s.w[layers],
+                       k.dz[layers]);
     HIVT_CHECK_LAUNCH(what);
     for (int l = layers; l >= 1; --l) {
-      const float* h_prev = l > 1 ? saved + s.h_off[l - 1] : x;
-      const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : x_ld;
-      if (params)
-        HIVT_TRY(hivt_linear_wgrad(dz, s.w[l], h_prev, h_prev_ld, B, s.w[l], s.w[l - 1], dw[l - 1], dbias[l - 1],
-                                   k.wgrad_ws, k.wgrad_bytes, stream));
-      if (l > 1 || dx != nullptr) {
-        float* dh = (l == 1) ? dx : other;
-        if (l > 1) {
-          HIVT_TRY(linear_bwd_data_gated(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], saved + s.h_off[l - 1],
-                                         s.w[l - 1], keep_scale, keep_scale * neg_slope, dh, s.w[l - 1], stream));
-        } else {
-          HIVT_TRY(hivt_linear_bwd_data(dz, s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f,
-                                        nullptr, 0, dh, s.w[l - 1], stream));
-        }
-        if (l > 1) {
-          float* t = dz;
-          dz = dh;
-          other = t;
-        }
+      if (l > 1) {
+        HIVT_TRY(linear_bwd_data_gated(k.dz[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1],
+                                       saved + s.h_off[l - 1], s.w[l - 1], keep_scale, keep_scale * neg_slope,
+                                       k.dz[l - 1], s.w[l - 1], stream));
+      } else if (dx != nullptr) {
+        HIVT_TRY(hivt_linear_bwd_data(k.dz[l], s.w[l], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], nullptr, 0, 1.0f,
+                                      nullptr, 0, dx, s.w[l - 1], stream));
       }
     }
   } else {
@@ -387,32 +391,37 @@ extern "C" int hivt_critic_bwd(const float* g_scores, const float* g_norm2, cons
     HIVT_CHECK_LAUNCH(what);
   }
 
-  if (g_norm2 != nullptr) {
+  if (penalty_chain) {
     // ---- gradient of ||dD/dx||^2: the second chain (weights only; the factors c_l are constants) ----
-    const bool accumulate = g_scores != nullptr;
-    float* e = k.a;
-    float* t = k.b;
     hipLaunchKernelGGL(row_scale_kernel, dim3(blocks_for(B * s.w[0])), dim3(256), 0, st,
-                       (const float*)(saved + s.g0_off), g_norm2, 2.0f, B, s.w[0], e);
+                       (const float*)(saved + s.g0_off), g_norm2, 2.0f, B, s.w[0], k.e[0]);
     HIVT_CHECK_LAUNCH(what);
-    for (int l = 1; l <= layers; ++l) {
-      // dW_l (+)= G_l^T e_{l-1}
-      if (accumulate)
-        HIVT_TRY(linear_wgrad_accumulate(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], dw[l - 1],
-                                         k.wgrad_ws, k.wgrad_bytes, stream));
-      else
-        HIVT_TRY(hivt_linear_wgrad(saved + s.g_off[l], s.w[l], e, s.w[l - 1], B, s.w[l], s.w[l - 1], dw[l - 1], nullptr,
-                                   k.wgrad_ws, k.wgrad_bytes, stream));
-      // e_l = (e_{l-1} W_l^T) * c_l
-      HIVT_TRY(linear_fwd_gated(e, s.w[l - 1], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], saved + s.h_off[l], s.w[l],
-                                keep_scale, keep_scale * neg_slope, t, s.w[l], stream));
-      float* sw = e;
-      e = t;
-      t = sw;
+    // e_l = (e_{l-1} W_l^T) * c_l
+    for (int l = 1; l <= layers; ++l)
+      HIVT_TRY(linear_fwd_gated(k.e[l - 1], s.w[l - 1], w[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1],
+                                saved + s.h_off[l], s.w[l], keep_scale, keep_scale * neg_slope, k.e[l], s.w[l], stream));
+  }
+
+  if (params) {
+    Terms t;
+    // output layer: dw_o = g^T h_L, db_o = sum g
+    if (scores_chain)
+      t.add(g_scores, 1, saved + s.h_off[layers], s.w[layers], B, 1, s.w[layers], dw[layers], dbias[layers], false, false);
+    for (int l = layers; l >= 1; --l) {
+      const float* h_prev = l > 1 ? saved + s.h_off[l - 1] : x;
+      const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : x_ld;
+      if (scores_chain)  // dW_l = dz_l^T h_{l-1}, db_l = column sums of dz_l
+        t.add(k.dz[l], s.w[l], h_prev, h_prev_ld, B, s.w[l], s.w[l - 1], dw[l - 1], dbias[l - 1], false, false);
+      if (penalty_chain)  // dW_l (+)= G_l^T e_{l-1}
+        t.add(saved + s.g_off[l], s.w[l], k.e[l - 1], s.w[l - 1], B, s.w[l], s.w[l - 1], dw[l - 1], nullptr, false,
+              scores_chain);
     }
-    // dw_o (+)= column sums of e_L (rows summed in a fixed order)
-    reduce_partials(e, (int)B, s.w[layers], dw[layers], st, accumulate);
-    HIVT_CHECK_LAUNCH(what);
+    HIVT_TRY(hivt_linear_wgrad_group(&t.row[0][0], t.count, k.wgrad_ws, k.wgrad_bytes, stream));
+    if (penalty_chain) {
+      // dw_o (+)= column sums of e_L (rows summed in a fixed order)
+      reduce_partials(k.e[layers], (int)B, s.w[layers], dw[layers], st, scores_chain);
+      HIVT_CHECK_LAUNCH(what);
+    }
   }
   return HIVT_OK;
 }

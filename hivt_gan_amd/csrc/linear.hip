@@ -13,6 +13,8 @@
 // fp32 in, fp32 accumulate: results equal an fmaf chain over k, which keeps the 1e-5 parity bar.
 #include "common.h"
 
+#include <vector>
+
 #include <math.h>
 
 #include <atomic>
@@ -678,13 +680,14 @@ struct WgradArgs {
   int32_t N, K, M, chunk_rows;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
-__global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
+// One workgroup's share: the [BM x BN] tile (tile_n, tile_k) of the partial sums of row chunk `chunk`.
+// zero_bias: the chunk's bias slots are cleared instead of filled (a term without a bias gradient that shares
+// its partial buffer with one that has it).
+template <int BM, int BN, bool VEC, bool DEEP, int PREC>
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int tile_n, int tile_k, int chunk, float* lds,
+                                           float (*bsum)[BM], bool zero_bias) {
   using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
-  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  __shared__ float bsum[kThreads / (BM / 4)][BM];
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
-  const int chunk = blockIdx.z;
+  const int row0 = tile_n * BM, col0 = tile_k * BN;
   const int m_begin = chunk * a.chunk_rows;
   const int m_end = min(a.M, m_begin + a.chunk_rows);
   Operand dy = a.dy, x = a.x;
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   }
   // bias gradient of this chunk = column sums of the dY rows this block staged (first column tile
   // only): thread t staged columns 4*(t % (BM/4)) .. +3 of every row it touched
-  if (a.bias_partial != nullptr && blockIdx.y == 0) {
+  if (a.bias_partial != nullptr && tile_k == 0) {
     constexpr int QUADS = BM / 4, GROUPS = kThreads / QUADS;
     const int q = threadIdx.x % QUADS, g = threadIdx.x / QUADS;
     bsum[g][4 * q + 0] = colsum.x;
@@ -719,9 +722,88 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
       float t = 0.0f;
 #pragma unroll
       for (int i = 0; i < GROUPS; ++i) t += bsum[i][threadIdx.x];
-      a.bias_partial[(int64_t)chunk * a.pitch + row0 + threadIdx.x] = t;
+      a.bias_partial[(int64_t)chunk * a.pitch + row0 + threadIdx.x] = zero_bias ? 0.0f : t;
     }
   }
+}
+
+template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
+__global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
+  using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  __shared__ float bsum[kThreads / (BM / 4)][BM];
+  wgrad_tile<BM, BN, VEC, DEEP, PREC>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds, bsum, false);
+}
+
+// Several small weight gradients in one launch: workgroup b belongs to the term whose block range holds b
+// and computes one (tile, chunk) of it exactly as linear_wgrad_kernel would.
+constexpr int kGroupMax = 16;
+
+struct WgradGroup {
+  WgradArgs item[kGroupMax];
+  int32_t first_block[kGroupMax + 1];
+  int32_t zero_bias[kGroupMax];
+  int32_t count;
+};
+
+template <int BM, int BN, int PREC>
+__global__ __launch_bounds__(kThreads) void linear_wgrad_group_kernel(const WgradGroup g) {
+  using C = Core<BM, BN, false, false, true, true, true, PREC>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  __shared__ float bsum[kThreads / (BM / 4)][BM];
+  int i = 0;
+  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
+  const WgradArgs& a = g.item[i];
+  const int local = (int)blockIdx.x - g.first_block[i];
+  const int tiles_n = (a.N + BM - 1) / BM, tiles_k = (a.K + BN - 1) / BN;
+  wgrad_tile<BM, BN, true, true, PREC>(a, local % tiles_n, (local / tiles_n) % tiles_k, local / (tiles_n * tiles_k), lds,
+                                      bsum, g.zero_bias[i] != 0);
+}
+
+// The reductions over the chunks of a group, in the association of reduce_rows_kernel<64, 4>: per term four
+// row slices summed in ascending order and combined in slice order; the terms of an entry are added in term
+// order.  One thread per output column.
+struct ReduceEntry {
+  const float* term_base[2];  // partial sums of up to two terms, [chunks][pitch] each
+  int64_t pitch;
+  float* out;
+  float* out1;      // columns at or beyond `split`
+  int32_t cols, split;
+  int32_t term_chunks[2];  // term_chunks[1] = 0: one term
+  int32_t accumulate;
+};
+
+struct ReduceGroup {
+  ReduceEntry e[kGroupMax];
+  int32_t first_block[kGroupMax + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) {
+  int i = 0;
+  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
+  const ReduceEntry& e = g.e[i];
+  const int c = ((int)blockIdx.x - g.first_block[i]) * 256 + (int)threadIdx.x;
+  if (c >= e.cols) return;
+  float total = 0.0f;
+#pragma unroll
+  for (int term = 0; term < 2; ++term) {
+    const int R = e.term_chunks[term];
+    if (R == 0) continue;
+    const float* base = e.term_base[term] + c;
+    const int per = (R + 3) / 4;
+    float t = 0.0f;
+    for (int sl = 0; sl < 4; ++sl) {
+      const int r0 = min(R, sl * per), r1 = min(R, r0 + per);
+      float s = 0.0f;
+      for (int r = r0; r < r1; ++r) s += base[(int64_t)r * e.pitch];
+      t = sl == 0 ? s : t + s;
+    }
+    total = term == 0 ? t : total + t;
+  }
+  if (c >= e.split && e.out1 == nullptr) return;  // bias columns of an entry without a bias gradient
+  float* dst = c < e.split ? e.out + c : e.out1 + (c - e.split);
+  *dst = e.accumulate ? *dst + total : total;
 }
 
 // out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: SLICES row slices are summed
@@ -1316,6 +1398,156 @@ int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int6
   return linear_wgrad_impl(dy, dy_ld, x, x_ld, M, N, K, dw, nullptr, workspace, workspace_bytes, stream, true);
 }
 }  // namespace hivt
+
+// ---------------------------------------------------------------------------------------------
+// Several weight gradients per call.  items: count x 10 int64 -- dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none),
+// flags (bit 0: add to what dw / dbias hold; bit 1: this term joins the item before it: same dw, its sum is
+// added to that item's, no bias term of its own).  Every result equals what hivt_linear_wgrad (or its
+// accumulating form) returns for the item; terms small enough for the grouped kernels share launches (sixteen
+// per launch), the rest go through the single-product path one by one.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct GroupItem {
+  const float* dy; int64_t dy_ld; const float* x; int64_t x_ld; int64_t M; int32_t N, K; float* dw; float* dbias;
+  bool accumulate, joins;
+  int chunks, chunk_rows, tiles;  // of the single-product path
+  bool groupable;
+  size_t ws_floats;               // its share of the workspace
+};
+
+int parse_group(const char* what, const int64_t* items, int32_t count, std::vector<GroupItem>& out) {
+  HIVT_REQUIRE(count >= 0 && (count == 0 || items != nullptr), HIVT_ERR_ARG, "%s: bad item table", what);
+  out.resize((size_t)count);
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t* t = items + (size_t)i * 10;
+    GroupItem& g = out[(size_t)i];
+    g.dy = reinterpret_cast<const float*>((uintptr_t)t[0]); g.dy_ld = t[1];
+    g.x = reinterpret_cast<const float*>((uintptr_t)t[2]); g.x_ld = t[3];
+    g.M = t[4]; g.N = (int32_t)t[5]; g.K = (int32_t)t[6];
+    g.dw = reinterpret_cast<float*>((uintptr_t)t[7]); g.dbias = reinterpret_cast<float*>((uintptr_t)t[8]);
+    g.accumulate = (t[9] & 1) != 0; g.joins = (t[9] & 2) != 0;
+    HIVT_REQUIRE(g.M >= 0 && g.M < ((int64_t)1 << 31) && t[5] > 0 && t[6] > 0 && t[5] < ((int64_t)1 << 24) &&
+                 t[6] < ((int64_t)1 << 24), HIVT_ERR_ARG, "%s: item %d: bad sizes", what, (int)i);
+    HIVT_REQUIRE(g.dw != nullptr, HIVT_ERR_ARG, "%s: item %d: dw is null", what, (int)i);
+    HIVT_REQUIRE(g.M == 0 || (g.dy && g.x), HIVT_ERR_ARG, "%s: item %d: null operand", what, (int)i);
+    if (g.joins) {
+      HIVT_REQUIRE(i > 0 && !out[(size_t)i - 1].joins && out[(size_t)i - 1].dw == g.dw && out[(size_t)i - 1].N == g.N &&
+                   out[(size_t)i - 1].K == g.K, HIVT_ERR_ARG,
+                   "%s: item %d joins an item that is not a plain item with the same dw and sizes", what, (int)i);
+      g.dbias = nullptr;
+    }
+    g.tiles = ((g.N + 63) / 64) * ((g.K + 127) / 128);
+    g.chunks = g.M > 0 ? pick_chunks(g.M, g.tiles) : 0;
+    g.chunk_rows = g.M > 0 ? (int)(((g.M + g.chunks - 1) / g.chunks + kBK - 1) / kBK * kBK) : 0;
+    if (g.M > 0) g.chunks = (int)((g.M + g.chunk_rows - 1) / g.chunk_rows);
+    const Operand a = make_operand(g.dy, g.dy_ld, g.N, (int32_t)g.M, false);
+    const Operand b = make_operand(g.x, g.x_ld, g.K, (int32_t)g.M, false);
+    g.groupable = g.M > 0 && a.vec_ok && b.vec_ok && g.chunks < 64 && (unsigned)(g.chunks * g.tiles) <= kSmallGrid;
+    g.ws_floats = align_up(hivt_linear_wgrad_workspace_bytes(g.M, g.N, g.K), 256) / sizeof(float);
+  }
+  // an entry (an item and the one that joins it) goes through the grouped kernels only as a whole
+  for (int32_t i = 0; i < count; ++i)
+    if (out[(size_t)i].joins && !(out[(size_t)i].groupable && out[(size_t)i - 1].groupable))
+      out[(size_t)i].groupable = out[(size_t)i - 1].groupable = false;
+  return HIVT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t hivt_linear_wgrad_group_workspace_bytes(const int64_t* items, int32_t count) {
+  std::vector<GroupItem> g;
+  if (parse_group("hivt_linear_wgrad_group_workspace_bytes", items, count, g) != HIVT_OK) return 0;
+  size_t floats = 64;
+  for (const GroupItem& it : g) floats += it.ws_floats;
+  return floats * sizeof(float);
+}
+
+extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void* workspace, size_t workspace_bytes,
+                                       hivt_stream_t stream) {
+  const char* what = "hivt_linear_wgrad_group";
+  std::vector<GroupItem> g;
+  { const int rc = parse_group(what, items, count, g); if (rc != HIVT_OK) return rc; }
+  if (count == 0) return HIVT_OK;
+  size_t need = 64;
+  for (const GroupItem& it : g) need += it.ws_floats;
+  HIVT_REQUIRE(workspace && workspace_bytes >= need * sizeof(float), HIVT_ERR_WORKSPACE, "%s: workspace too small", what);
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_WGRAD) != 0;
+  float* ws = reinterpret_cast<float*>(workspace);
+  std::vector<float*> region((size_t)count);
+  {
+    size_t off = 0;
+    for (int32_t i = 0; i < count; ++i) { region[(size_t)i] = ws + off; off += g[(size_t)i].ws_floats; }
+  }
+  // terms outside the grouped kernels' range: the single-product path, in item order
+  for (int32_t i = 0; i < count; ++i) {
+    const GroupItem& it = g[(size_t)i];
+    if (it.groupable) continue;
+    const int rc = linear_wgrad_impl(it.dy, it.dy_ld, it.x, it.x_ld, it.M, it.N, it.K, it.dw, it.dbias, region[(size_t)i],
+                                     it.ws_floats * sizeof(float), stream, it.accumulate || it.joins);
+    if (rc != HIVT_OK) return rc;
+  }
+  // grouped: the products, sixteen terms per launch ...
+  WgradGroup wg{};
+  auto flush_products = [&]() {
+    if (wg.count == 0) return;
+    const unsigned blocks = (unsigned)wg.first_block[wg.count];
+    if (bf16)
+      hipLaunchKernelGGL((linear_wgrad_group_kernel<64, 128, PREC_BF16>), dim3(blocks), dim3(kThreads), 0, s, wg);
+    else
+      hipLaunchKernelGGL((linear_wgrad_group_kernel<64, 128, PREC_F32>), dim3(blocks), dim3(kThreads), 0, s, wg);
+    wg = WgradGroup{};
+  };
+  for (int32_t i = 0; i < count; ++i) {
+    const GroupItem& it = g[(size_t)i];
+    if (!it.groupable) continue;
+    // a joining term lays its chunks out like the item it joins (bias slots included, cleared)
+    const GroupItem& head = it.joins ? g[(size_t)i - 1] : it;
+    const int64_t pitch = (int64_t)head.N * head.K + (head.dbias ? head.N : 0);
+    float* base = region[(size_t)i];
+    WgradArgs a{};
+    a.dy = make_operand(it.dy, it.dy_ld, it.N, (int32_t)it.M, false);
+    a.x = make_operand(it.x, it.x_ld, it.K, (int32_t)it.M, false);
+    a.partial = base;
+    a.pitch = pitch;
+    a.bias_partial = head.dbias ? base + (size_t)it.N * it.K : nullptr;
+    a.N = it.N; a.K = it.K; a.M = (int32_t)it.M; a.chunk_rows = it.chunk_rows;
+    wg.item[wg.count] = a;
+    wg.zero_bias[wg.count] = it.joins ? 1 : 0;
+    wg.first_block[wg.count + 1] = wg.first_block[wg.count] + it.tiles * it.chunks;
+    if (++wg.count == kGroupMax) flush_products();
+  }
+  flush_products();
+  HIVT_CHECK_LAUNCH(what);
+  // ... and the sums over their chunks
+  ReduceGroup rg{};
+  auto flush_sums = [&]() {
+    if (rg.count == 0) return;
+    hipLaunchKernelGGL(reduce_group_kernel, dim3((unsigned)rg.first_block[rg.count]), dim3(256), 0, s, rg);
+    rg = ReduceGroup{};
+  };
+  for (int32_t i = 0; i < count; ++i) {
+    const GroupItem& it = g[(size_t)i];
+    if (!it.groupable || it.joins) continue;
+    const bool joined = i + 1 < count && g[(size_t)i + 1].joins;
+    ReduceEntry e{};
+    e.term_base[0] = region[(size_t)i];
+    e.term_base[1] = joined ? region[(size_t)i + 1] : nullptr;
+    e.pitch = (int64_t)it.N * it.K + (it.dbias ? it.N : 0);
+    e.out = it.dw; e.out1 = it.dbias;
+    e.cols = (int32_t)e.pitch; e.split = it.N * it.K;
+    e.term_chunks[0] = it.chunks;
+    e.term_chunks[1] = joined ? g[(size_t)i + 1].chunks : 0;
+    e.accumulate = it.accumulate ? 1 : 0;
+    rg.e[rg.count] = e;
+    rg.first_block[rg.count + 1] = rg.first_block[rg.count] + (e.cols + 255) / 256;
+    if (++rg.count == kGroupMax) flush_sums();
+  }
+  flush_sums();
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
 
 // Workgroups of the LayerNorm-backward kernel = rows of its partial-sum buffer: enough waves to keep
 // HBM busy on long inputs, few enough that the reduction over the partial rows stays short.

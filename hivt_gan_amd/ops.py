@@ -572,6 +572,99 @@ def set_matmul_precision(precision: str) -> str:
     return "bf16"
 
 
+def linear_wgrad_group(terms) -> None:
+    """Several weight gradients in one library call.  ``terms``: tuples ``(dy [M, N], x [M, K], dw [N, K],
+    dbias [N] or None, accumulate, joins)`` -- ``dw (+)= dy^T x``, ``dbias (+)= column sums of dy``; ``joins``:
+    the term adds to the same ``dw`` as the term before it.  Results equal one ``hivt_linear_wgrad`` call per
+    term bit for bit; terms of a few thousand rows share launches."""
+    if not terms:
+        return
+    flat = []
+    for dy, x, dw, db, accumulate, joins in terms:
+        m, n = dy.shape
+        k = x.shape[1]
+        if x.shape[0] != m or tuple(dw.shape) != (n, k) or not dw.is_contiguous() or (db is not None and db.numel() != n):
+            raise ValueError("linear_wgrad_group: operand shapes do not fit")
+        flat += [dy.data_ptr(), dy.stride(0) if m > 1 else n, x.data_ptr(), x.stride(0) if m > 1 else k, m, n, k,
+                 dw.data_ptr(), db.data_ptr() if db is not None else 0, (1 if accumulate else 0) | (2 if joins else 0)]
+    _launch_wgrad_group(flat, len(terms), terms[0][0].device)
+
+
+def _launch_wgrad_group(flat, count: int, dev) -> None:
+    table = (ctypes.c_int64 * len(flat))(*flat)
+    ws = _workspace(_lib.value("hivt_linear_wgrad_group_workspace_bytes", table, count), dev)
+    _lib.call("hivt_linear_wgrad_group", table, count, _p(ws), ws.numel(), torch._C._cuda_getCurrentRawStream(dev.index))
+
+
+# Weight gradients are leaves of the backward pass: nothing but the optimizer reads them.  Inside
+# ``deferred_weight_grads()`` the products of layers with at most ``_DEFER_MAX_ROWS`` rows (a launch each for
+# the product and for the sum over its chunks, all latency at that size) are collected while the backward pass
+# runs and issued together when it ends (a callback of the autograd engine), a few launches for all of them.
+# The gradient tensors handed to autograd exist from the start and are filled by that call; nothing may read
+# a parameter's ``.grad`` from a hook before the pass has ended.
+_DEFER_MAX_ROWS = 8192
+_deferred: Optional[list] = None
+
+
+class deferred_weight_grads:
+    """Context manager; see above.  Not re-entrant across threads: one training step at a time."""
+
+    def __enter__(self):
+        global _deferred
+        self._prev = _deferred
+        _deferred = []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred
+        try:
+            if exc[0] is None:
+                flush_weight_grads()
+        finally:
+            _deferred = self._prev
+        return False
+
+
+def flush_weight_grads() -> None:
+    """Issues the collected weight gradients (runs by itself at the end of every backward pass)."""
+    queue = _deferred
+    if not queue:
+        return
+    flat, keep, dev = [], [], queue[0][1]
+    for item, _, tensors in queue:
+        flat += item
+        keep.append(tensors)
+    count = len(queue)
+    del queue[:]
+    _launch_wgrad_group(flat, count, dev)
+    del keep  # the operands stayed alive until the call that reads them was issued
+
+
+def _all_leaves(*tensors) -> bool:
+    """True if every given tensor is a leaf of the autograd graph (a parameter, not a slice or a concatenation
+    of parameters): only then does nothing but the optimizer read its gradient."""
+    return all(t is None or t.is_leaf for t in tensors)
+
+
+def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int, n: int, k: int, dev,
+                 bias: bool = True, leaves: bool = False):
+    """``(dW [n, k], db [n] or None)`` of ``y = x W^T + b`` from ``g = dL/dy`` [m, n] and ``x`` [m, k].
+    ``leaves``: weight and bias are leaves of the graph, so the product may be deferred."""
+    dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+    db = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
+    if leaves and _deferred is not None and 0 < m <= _DEFER_MAX_ROWS:
+        if not _deferred:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+        # addresses, not tensors, of the results: autograd takes a gradient over only while it holds the one
+        # reference to it
+        _deferred.append(([g.data_ptr(), g_ld, x.data_ptr(), x_ld, m, n, k, dw.data_ptr(),
+                           db.data_ptr() if bias else 0, 0], dev, (g, x)))
+        return dw, db
+    ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
+    _lib.call("hivt_linear_wgrad", _p(g), g_ld, _p(x), x_ld, m, n, k, _p(dw), _p(db), _p(ws), ws.numel(), _stream(g))
+    return dw, db
+
+
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
@@ -619,6 +712,7 @@ class _FusedLinear(torch.autograd.Function):
                    tuple(residual.shape) if residual is not None else None)
         ctx.res_leaf = residual is not None and residual.is_leaf
         ctx.add_leaf = add is not None and add.is_leaf
+        ctx.param_leaves = _all_leaves(weight, bias)
         return y.view(*lead, n)
 
     @staticmethod
@@ -654,11 +748,8 @@ class _FusedLinear(torch.autograd.Function):
                       _p(dx), k, s)
             dx = dx.view(*lead, k)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty(n, k, dtype=torch.float32, device=dev)
-            db = torch.empty(n, dtype=torch.float32, device=dev) if has_bias else None
-            ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
-            _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(x2), x2.stride(0), m, n, k, _p(dw), _p(db),
-                      _p(ws), ws.numel(), s)
+            dw, db = _weight_grad(dz, dz.stride(0), x2, x2.stride(0), m, n, k, dev, bias=has_bias,
+                                  leaves=ctx.param_leaves)
         dadd = None
         if has_add and ctx.needs_input_grad[3]:
             if add_index is None:
@@ -725,6 +816,7 @@ class _PairLinear(torch.autograd.Function):
                   EPI_NONE, 1.0, 0.0, 0, None, None, 0, m, n, k, _p(y), n, None, 0, None, _stream(x))
         ctx.save_for_backward(x2, w)
         ctx.cfg = (tuple(lead), int(w_a.shape[0]))
+        ctx.param_leaves = _all_leaves(w_a, b_a, w_b, b_b)
         return y.view(*lead, n)
 
     @staticmethod
@@ -743,11 +835,7 @@ class _PairLinear(torch.autograd.Function):
             _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0, None, 0,
                       _p(dx), k, s)
             dx = dx.view(*lead, k)
-        dw = torch.empty(n, k, dtype=torch.float32, device=dev)
-        db = torch.empty(n, dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
-        _lib.call("hivt_linear_wgrad", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), m, n, k, _p(dw), _p(db), _p(ws),
-                  ws.numel(), s)
+        dw, db = _weight_grad(dy2, dy2.stride(0), x2, x2.stride(0), m, n, k, dev, leaves=ctx.param_leaves)
         return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:]
 
 
@@ -1222,6 +1310,7 @@ class _PreNormFeedForward(torch.autograd.Function):
                   0, None, s)
         ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, h, w1c, w2c, DEVICE_SEED if p2 > 0.0 else None)
         ctx.cfg = (tuple(lead), float(p1), float(p2), int(seed2))
+        ctx.param_leaves = _all_leaves(w1, b1, w2, b2)
         return y.view(*lead, d)
 
     @staticmethod
@@ -1240,20 +1329,13 @@ class _PreNormFeedForward(torch.autograd.Function):
         else:
             dz2 = dy2
         # second Linear: weight gradient, then the data gradient gated by the ReLU / dropout of its input
-        dw2 = torch.empty(d, hdim, dtype=torch.float32, device=dev)
-        db2 = torch.empty(d, dtype=torch.float32, device=dev)
-        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", m, d, hdim),
-                            _lib.query("hivt_linear_wgrad_workspace_bytes", m, hdim, d),
-                            _lib.query("hivt_ln_bwd_workspace_bytes", m, d)), dev)
-        _lib.call("hivt_linear_wgrad", _p(dz2), dz2.stride(0), _p(h), hdim, m, d, hdim, _p(dw2), _p(db2), _p(ws),
-                  ws.numel(), s)
+        dw2, db2 = _weight_grad(dz2, dz2.stride(0), h, hdim, m, d, hdim, dev, leaves=ctx.param_leaves)
+        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, d), dev)
         dz1 = torch.empty(m, hdim, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
                   1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
         # first Linear
-        dw1 = torch.empty(hdim, d, dtype=torch.float32, device=dev)
-        db1 = torch.empty(hdim, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_wgrad", _p(dz1), hdim, _p(xn), d, m, hdim, d, _p(dw1), _p(db1), _p(ws), ws.numel(), s)
+        dw1, db1 = _weight_grad(dz1, hdim, xn, d, m, hdim, d, dev, leaves=ctx.param_leaves)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0, _p(dxn), d, s)
         # LayerNorm, plus the residual route's gradient (dy itself)
@@ -1316,6 +1398,7 @@ class _PreNormTemporalAttention(torch.autograd.Function):
         ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, qkv, o, lse, w_in_c, w_out_c,
                               DEVICE_SEED if (p_attn > 0.0 or p_out > 0.0) else None)
         ctx.cfg = (s_len, n, int(num_heads), float(p_attn), float(p_out), int(seed_attn), int(seed_out))
+        ctx.param_leaves = _all_leaves(w_in, b_in, w_out, b_out)
         return y.view(s_len, n, d)
 
     @staticmethod
@@ -1333,23 +1416,15 @@ class _PreNormTemporalAttention(torch.autograd.Function):
                       d, st)
         else:
             dz = dy2
-        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", m, d, d),
-                            _lib.query("hivt_linear_wgrad_workspace_bytes", m, 3 * d, d),
-                            _lib.query("hivt_ln_bwd_workspace_bytes", m, d)), dev)
-        dw_out = torch.empty(d, d, dtype=torch.float32, device=dev)
-        db_out = torch.empty(d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_wgrad", _p(dz), dz.stride(0), _p(o), d, m, d, d, _p(dw_out), _p(db_out), _p(ws),
-                  ws.numel(), st)
+        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, d), dev)
+        dw_out, db_out = _weight_grad(dz, dz.stride(0), o, d, m, d, d, dev, leaves=ctx.param_leaves)
         do = torch.empty(m, d, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, None, 0,
                   _p(do), d, st)
         dqkv = torch.empty(m, 3 * d, dtype=torch.float32, device=dev)
         _lib.call("hivt_temporal_attn_bwd", _p(do), _p(qkv), _p(o), _p(lse), s_len, n, d, num_heads, p_attn, seed_attn,
                   _p(seed_dev), _p(dqkv), st)
-        dw_in = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
-        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_wgrad", _p(dqkv), 3 * d, _p(xn), d, m, 3 * d, d, _p(dw_in), _p(db_in), _p(ws), ws.numel(),
-                  st)
+        dw_in, db_in = _weight_grad(dqkv, 3 * d, xn, d, m, 3 * d, d, dev, leaves=ctx.param_leaves)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, None, 0,
                   _p(dxn), d, st)
@@ -1408,6 +1483,7 @@ class _GatedUpdateTail(torch.autograd.Function):
         linear(upd, d, w_out_c, b_out_c, d, y, p_out, seed_out, r2, r2.stride(0))
         ctx.save_for_backward(agg2, c2, ih, hs, upd, w_ih_c, w_hs, w_out_c, DEVICE_SEED if p_out > 0.0 else None)
         ctx.cfg = (float(p_out), int(seed_out), tuple(res.shape))
+        ctx.param_leaves = _all_leaves(w_ih, b_ih, w_hh, b_hh, w_self, b_self, w_out, b_out)
         ctx.res_leaf = res.is_leaf
         return y
 
@@ -1426,14 +1502,9 @@ class _GatedUpdateTail(torch.autograd.Function):
                       d, st)
         else:
             dz = dy2
-        ws = _workspace(max(_lib.query("hivt_linear_wgrad_workspace_bytes", n, d, d),
-                            _lib.query("hivt_linear_wgrad_workspace_bytes", n, 2 * d, d)), dev)
 
         def wgrad(g, g_ld, x, x_ld, rows_out):
-            dw = torch.empty(rows_out, d, dtype=torch.float32, device=dev)
-            db = torch.empty(rows_out, dtype=torch.float32, device=dev)
-            _lib.call("hivt_linear_wgrad", _p(g), g_ld, _p(x), x_ld, n, rows_out, d, _p(dw), _p(db), _p(ws), ws.numel(), st)
-            return dw, db
+            return _weight_grad(g, g_ld, x, x_ld, n, rows_out, d, dev, leaves=ctx.param_leaves)
 
         def data_grad(g, g_ld, w, rows_out, add=None):
             dx = torch.empty(n, d, dtype=torch.float32, device=dev)

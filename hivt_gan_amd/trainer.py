@@ -20,6 +20,7 @@ additionally brings the node / lane / pair tensors to fixed shapes for callers t
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -259,6 +260,7 @@ class GanTrainer:
             if distributed is None else distributed
         self.edge_capacity = tuple(int(c) for c in edge_capacity) if edge_capacity is not None else None
         self.sync_logs = bool(sync_logs)
+        self.defer_weight_grads = True
         if self.edge_capacity is not None:
             if not next(model.parameters()).is_cuda:
                 raise RuntimeError("the read-back-free step needs the model on the GPU")
@@ -339,13 +341,24 @@ class GanTrainer:
                 out[k] = vals[i] / vals[n + i].clamp(min=1.0)
         return out
 
+    def _weight_grad_scope(self):
+        """Small weight-gradient products of a backward pass are issued together at its end, unless grad-ready
+        hooks (overlapped data-parallel reduction) read gradients while the pass is still running."""
+        from . import ops
+        hooked = self.distributed and any(b.overlap for b in self.buckets.values())
+        if self.defer_weight_grads and not hooked and next(self.model.parameters()).is_cuda:
+            return ops.deferred_weight_grads()
+        return contextlib.nullcontext()
+
     def step(self, data) -> Dict[str, torch.Tensor]:
         sync = (self._sync_override or _DataParallelSync(self)) if self.distributed else None
         if self.edge_capacity is None:
-            logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
+            with self._weight_grad_scope():
+                logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
             return self.reduce_logs(logs) if (self.distributed and self.sync_logs) else logs
         data["edge_capacity"] = self.edge_capacity
-        logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
+        with self._weight_grad_scope():
+            logs = self.model.training_step(data, self.opt_g, self.opt_d, sync)
         if self.distributed and self.sync_logs:
             logs = self.reduce_logs(logs)
         if self._overflows is None:

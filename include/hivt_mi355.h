@@ -290,6 +290,17 @@ int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_
                       int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
                       hivt_stream_t stream);
 
+/* Several weight gradients in one call (models' backward passes hold dozens of them at a few thousand rows,
+ * where a launch per product and per sum is all latency).  `items` holds `count` rows of ten int64:
+ *   dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none), flags
+ * flags bit 0: the sums are added to what dw / dbias hold; bit 1: the term joins the item before it (same dw,
+ * N, K; its sum is added to that item's; no bias term).  Every result is bit-identical to hivt_linear_wgrad on
+ * the same item (torch.nn.Linear's weight.grad / bias.grad, as `loss.backward()` fills them in
+ * models/hivt.py:283,312,325).  Terms of fewer than 64 row chunks share launches, sixteen terms per launch. */
+size_t hivt_linear_wgrad_group_workspace_bytes(const int64_t* items, int32_t count);
+int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void* workspace, size_t workspace_bytes,
+                            hivt_stream_t stream);
+
 /* Stand-alone LayerNorm forward over the last dimension (N <= 128): y = gamma * (x - mean) * rstd + beta,
  * stats float [M,2] = (mean, rstd) per row for hivt_ln_bwd (called with z = x, relu = 0).  Replaces the
  * nn.LayerNorm in front of the attention and feed-forward blocks (models/local_encoder.py:119-120,
