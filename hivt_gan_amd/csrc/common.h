@@ -121,4 +121,10 @@ __device__ __forceinline__ float uniform01_u32(uint64_t seed, uint32_t index) {
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
+// Draw of the dropout masks of the dense layers' epilogues (and of the kernel that applies the same mask to the
+// gradient): the 32-bit mix on the low half of the element index, the high half folded into the seed.
+__device__ __forceinline__ float dropout_uniform(uint64_t seed, uint64_t index) {
+  return uniform01_u32(seed + (index >> 32) * 0x9E3779B97F4A7C15ull, (uint32_t)index);
+}
+
 }  // namespace hivt

@@ -13,6 +13,7 @@
 // fp32 in, fp32 accumulate: results equal an fmaf chain over k, which keeps the 1e-5 parity bar.
 #include "common.h"
 
+#include <algorithm>
 #include <vector>
 
 #include <math.h>
@@ -31,6 +32,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
 constexpr unsigned kSmallGrid = 384;  // workgroups: up to 1.5 per compute unit
+#ifndef HIVT_DEPTH4
+#define HIVT_DEPTH4 0
+#endif
+#ifndef HIVT_INTERLEAVE
+#define HIVT_INTERLEAVE 1
+#endif
 
 enum Epilogue : int { EPI_NONE = 0, EPI_RELU = 1, EPI_LN = 2, EPI_LN_RELU = 3 };
 
@@ -70,7 +77,9 @@ enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
 // 16-byte operand reads of 16 consecutive rows then start on 16 distinct groups of four banks); values are
 // rounded on their way from the fp32 registers to LDS, sums that leave the stage stay fp32.  PREC_SPLIT
 // keeps a second image of the same shape (the lo parts) PLANE_H halves behind the first.
-template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, int PREC = PREC_F32>
+// MASKED = false: the caller guarantees that every element the stage loads lies inside the operand (a tile in
+// the interior, whole reduction steps), so the validity bits are neither built nor applied.
+template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, int PREC = PREC_F32, bool MASKED = true>
 struct Stage {
   static constexpr bool BF16 = PREC != PREC_F32;
   static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
@@ -138,6 +147,13 @@ struct Stage {
 
   // One float4 of the staged step (r < NVEC) goes to LDS; store() sends all of them.
   __device__ __forceinline__ float4 masked(int r) const {
+    if constexpr (!MASKED) return v[r];
+    return zero_invalid(r);
+  }
+
+  // The running column sums (ACCUM) always go by the validity bits: the deep routes stage steps past the end
+  // of the reduction range, which are never multiplied but would be summed.
+  __device__ __forceinline__ float4 zero_invalid(int r) const {
     const unsigned m = ok >> (4 * r);
     float4 val;
     val.x = (m & 1u) ? v[r].x : 0.0f;
@@ -152,10 +168,11 @@ struct Stage {
       if ((r & 1) == 0) return;  // leaves together with its odd neighbour
       const float4 lo = masked(r - 1), hi = masked(r);
       if (ACCUM) {
-        colsum.x += lo.x + hi.x;
-        colsum.y += lo.y + hi.y;
-        colsum.z += lo.z + hi.z;
-        colsum.w += lo.w + hi.w;
+        const float4 sl = MASKED ? lo : zero_invalid(r - 1), sh = MASKED ? hi : zero_invalid(r);
+        colsum.x += sl.x + sh.x;
+        colsum.y += sl.y + sh.y;
+        colsum.z += sl.z + sh.z;
+        colsum.w += sl.w + sh.w;
       }
       const f32x4 fl = {lo.x, lo.y, lo.z, lo.w}, fh = {hi.x, hi.y, hi.z, hi.w};
       const s16x4 bl = __builtin_bit_cast(s16x4, __builtin_convertvector(fl, bf16x4));
@@ -170,17 +187,13 @@ struct Stage {
       return;
     }
     const int idx = tid + r * kThreads;
-    const unsigned m = ok >> (4 * r);
-    float4 val;
-    val.x = (m & 1u) ? v[r].x : 0.0f;
-    val.y = (m & 2u) ? v[r].y : 0.0f;
-    val.z = (m & 4u) ? v[r].z : 0.0f;
-    val.w = (m & 8u) ? v[r].w : 0.0f;
+    const float4 val = masked(r);
     if (ACCUM) {
-      colsum.x += val.x;
-      colsum.y += val.y;
-      colsum.z += val.z;
-      colsum.w += val.w;
+      const float4 sv = MASKED ? val : zero_invalid(r);
+      colsum.x += sv.x;
+      colsum.y += sv.y;
+      colsum.z += sv.z;
+      colsum.w += sv.w;
     }
     if (BF16) {
       const f32x4 f = {val.x, val.y, val.z, val.w};
@@ -223,7 +236,7 @@ struct Tail {
   const int32_t* add_index = nullptr;  // optional: row gr adds add[add_index[gr]] (rows of a small table)
   int32_t add_rows = 0;                // rows of that table; indices are clamped into it
   float neg_slope = 1.0f;              // LeakyReLU slope for negative values (1 = identity), applied before dropout
-  float drop_p = 0.0f;                 // dropout probability; the mask is uniform01(seed, row * cols + col) >= p
+  float drop_p = 0.0f;                 // dropout probability; the mask is dropout_uniform(seed, row * cols + col) >= p
   uint64_t seed = 0;
   const uint64_t* seed_ptr = nullptr;  // optional device-side value added to seed
   const float* residual = nullptr;
@@ -236,15 +249,18 @@ struct Tail {
   float mask_neg_scale = 0.0f;
 };
 
-// DEEP: two register sets per operand, so that the global loads of step s + 2 are in flight while
-// step s is multiplied (used for small grids, where no other workgroup shares the compute unit to
-// hide the load latency behind; it costs registers, hence occupancy, on large grids).
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, bool DEEP = false, int PREC = PREC_F32>
+// DEEP = 1 / 2: two / four register sets per operand, so that the global loads of steps s + 2 (.. s + 4) are
+// in flight while step s is multiplied (for grids where no other workgroup shares the compute unit to hide
+// the load latency behind; it costs registers, hence occupancy, on large grids).  With four sets a reduction
+// of 128 has all of its loads in flight at once: one memory latency per tile instead of two.
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, int DEEP = 0, int PREC = PREC_F32>
 struct Core {
   static constexpr bool BF16 = PREC != PREC_F32;
   static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
-  using SA = Stage<BM, TA, VEC, ACC_A, PREC>;
-  using SB = Stage<BN, TB, VEC, false, PREC>;
+  template <bool MASKED> using StageA = Stage<BM, TA, VEC, ACC_A, PREC, MASKED>;
+  template <bool MASKED> using StageB = Stage<BN, TB, VEC, false, PREC, MASKED>;
+  using SA = StageA<true>;   // sizes and pitches do not depend on the masking
+  using SB = StageB<true>;
   static constexpr int A_FLOATS = SA::FLOATS;
   static constexpr int B_FLOATS = SB::FLOATS;
   static constexpr int C_PITCH = BN + 4;
@@ -260,6 +276,22 @@ struct Core {
   __device__ static void accumulate(const Operand& a, const Operand& b, int row0, int col0, int red_begin,
                                     int red_end, float* lds, f32x16& acc0, f32x16& acc1,
                                     float4* a_colsum = nullptr) {
+    // a tile in the interior of both operands whose reduction range is whole steps (whole rounds of the
+    // register sets on the deep routes, which run the padded steps too) needs no validity masks
+    constexpr int ROUND = kBK * (DEEP > 0 ? 2 * DEEP : 1);
+    const bool whole = row0 + BM <= a.rows && col0 + BN <= b.rows && red_end <= a.red && red_end <= b.red &&
+                       (red_end - red_begin) % ROUND == 0 && red_end > red_begin;
+    if (whole)
+      accumulate_impl<false>(a, b, row0, col0, red_begin, red_end, lds, acc0, acc1, a_colsum);
+    else
+      accumulate_impl<true>(a, b, row0, col0, red_begin, red_end, lds, acc0, acc1, a_colsum);
+  }
+
+  template <bool MASKED>
+  __device__ static void accumulate_impl(const Operand& a, const Operand& b, int row0, int col0, int red_begin,
+                                         int red_end, float* lds, f32x16& acc0, f32x16& acc1, float4* a_colsum) {
+    using SA = StageA<MASKED>;
+    using SB = StageB<MASKED>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
@@ -297,25 +329,41 @@ struct Core {
             b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 32 * SB::PITCH_H + 16 * g);
           }
         }
+        // HIVT_FENCE: nothing moves across -- the conversions of the operand set that is being published
+        // (vector ALU work inside between()) stay between the matrix instructions they are written between
+        // instead of queueing up behind the last one
+#if HIVT_INTERLEAVE
+#define HIVT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HIVT_FENCE() do { } while (0)
+#endif
+        HIVT_FENCE();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if constexpr (SPLIT3) {  // the small terms first, the leading one last
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], b0h[g], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], b1h[g], acc1, 0, 0, 0);
+            HIVT_FENCE();
             between(8 * g + 1);
+            HIVT_FENCE();
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b0l[g], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b1l[g], acc1, 0, 0, 0);
+            HIVT_FENCE();
             between(8 * g + 3);
+            HIVT_FENCE();
           }
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b0h[g], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], b1h[g], acc1, 0, 0, 0);
+          HIVT_FENCE();
           if constexpr (!SPLIT3) {
             between(8 * g + 1);
             between(8 * g + 3);
           }
           between(8 * g + 5);
           between(8 * g + 7);
+          HIVT_FENCE();
         }
+#undef HIVT_FENCE
         return;
       }
       const int ao = cur + wr * 32 + lo;
@@ -353,7 +401,7 @@ struct Core {
           pb.store_piece(lds + dst + A_FLOATS, tid, piece - SA::NVEC);
       };
     };
-    if constexpr (!DEEP) {
+    if constexpr (DEEP == 0) {
       SA sa;
       SB sb;
       if (steps > 0) {
@@ -381,34 +429,42 @@ struct Core {
       if (ACC_A) *a_colsum = sa.colsum;
     } else {
       // Every load and every LDS store below is unconditional: loads past the end of the reduction
-      // range are clamped in bounds and masked to zero (Stage::load), and an odd step count is padded
-      // by one all-zero step.  Straight-line code lets the compiler count the loads in flight, so
-      // waiting for one register set leaves the other set's loads outstanding.
-      SA sa[2];
-      SB sb[2];
-      sa[0].load(a, row0, red_begin, tid);
-      sb[0].load(b, col0, red_begin, tid);
-      sa[1].load(a, row0, red_begin + kBK, tid);
-      sb[1].load(b, col0, red_begin + kBK, tid);
+      // range are clamped in bounds and masked to zero (Stage::load), and the step count is padded to a
+      // multiple of the set count by all-zero steps.  Straight-line code lets the compiler count the loads
+      // in flight, so waiting for one register set leaves the other sets' loads outstanding.
+      constexpr int D = 2 * DEEP;  // register sets = steps in flight; set j holds steps j, j + D, ...
+      SA sa[D];
+      SB sb[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        sa[j].load(a, row0, red_begin + j * kBK, tid);
+        sb[j].load(b, col0, red_begin + j * kBK, tid);
+      }
       sa[0].store(lds, tid);
       sb[0].store(lds + A_FLOATS, tid);
       __syncthreads();
       HIVT_STAMP(1);
-      for (int s = 0; s < steps; s += 2) {
-        // even step: multiply buffer 0, fetch step s + 2 into set 0, publish set 1 (step s + 1) in buffer 1
-        sa[0].load(a, row0, red_begin + (s + 2) * kBK, tid);
-        sb[0].load(b, col0, red_begin + (s + 2) * kBK, tid);
-        multiply(0, publish(sa[1], sb[1], BUF));
-        __syncthreads();
-        // odd step: multiply buffer 1, fetch step s + 3 into set 1, publish set 0 (step s + 2) in buffer 0
-        sa[1].load(a, row0, red_begin + (s + 3) * kBK, tid);
-        sb[1].load(b, col0, red_begin + (s + 3) * kBK, tid);
-        multiply(BUF, publish(sa[0], sb[0], 0));
-        __syncthreads();
+      for (int s = 0; s < steps; s += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          // step s + j: multiply buffer j & 1; set j (its step is in LDS already) fetches step s + j + D; set
+          // j + 1 (step s + j + 1) is published in the other buffer while the matrix unit is busy
+          sa[j].load(a, row0, red_begin + (s + j + D) * kBK, tid);
+          sb[j].load(b, col0, red_begin + (s + j + D) * kBK, tid);
+          multiply((j & 1) * BUF, publish(sa[(j + 1) % D], sb[(j + 1) % D], ((j + 1) & 1) * BUF));
+          __syncthreads();
+        }
       }
       if (ACC_A) {
-        const float4 c0 = sa[0].colsum, c1 = sa[1].colsum;
-        *a_colsum = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
+        float4 c = sa[0].colsum;
+#pragma unroll
+        for (int j = 1; j < D; ++j) {
+          c.x += sa[j].colsum.x;
+          c.y += sa[j].colsum.y;
+          c.z += sa[j].colsum.z;
+          c.w += sa[j].colsum.w;
+        }
+        *a_colsum = c;
       }
     }
   }
@@ -443,9 +499,122 @@ struct Core {
   // hold 32 consecutive columns of one row (a 128-byte segment) and the high lanes the row 4 below.
   // The added / residual values of all 16 registers are requested first and consumed afterwards, so
   // their latencies overlap instead of adding up.
+  // The same for a tile that lies inside the output (no bounds to check): every feature of the tail is one
+  // pass over the sixteen register pairs behind ONE uniform branch, addresses are 32-bit offsets from the
+  // tile's corner, and the dropout draws come from the 32-bit mix.
+  template <bool RELU>
+  __device__ static void store_interior(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int cols,
+                                        float* __restrict__ out, int64_t out_ld, const Tail& t, float2 bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int lrow = wr * 32 + 4 * hi, lcol = wc * 64 + lo;
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v0[r] = acc0[r] + bias.x;
+      v1[r] = acc1[r] + bias.y;
+    }
+    if (t.add != nullptr) {
+      const float* corner = t.add + (int64_t)row0 * t.add_ld + col0;
+      const int ld = (int)t.add_ld, off = lrow * ld + lcol;
+      float a0[16], a1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = off + ((r & 3) + 8 * (r >> 2)) * ld;
+        a0[r] = corner[o];
+        a1[r] = corner[o + 32];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] += a0[r];
+        v1[r] += a1[r];
+      }
+    }
+    if (RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] = fmaxf(v0[r], 0.0f);
+        v1[r] = fmaxf(v1[r], 0.0f);
+      }
+    } else if (t.neg_slope != 1.0f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] = v0[r] > 0.0f ? v0[r] : v0[r] * t.neg_slope;
+        v1[r] = v1[r] > 0.0f ? v1[r] : v1[r] * t.neg_slope;
+      }
+    }
+    if (t.drop_p > 0.0f) {
+      const float keep_scale = 1.0f / (1.0f - t.drop_p);
+      const uint64_t seed = t.seed + (t.seed_ptr != nullptr ? *t.seed_ptr : 0ull);
+      const uint64_t first = (uint64_t)(row0 + lrow) * (uint64_t)cols + (uint64_t)(col0 + lcol);
+      if (((uint64_t)(row0 + BM) * (uint64_t)cols >> 32) == 0) {  // the tile's indices fit 32 bits (uniform)
+        const uint32_t f32 = (uint32_t)first, c32 = (uint32_t)cols;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t i0 = f32 + (uint32_t)((r & 3) + 8 * (r >> 2)) * c32;
+          v0[r] = uniform01_u32(seed, i0) >= t.drop_p ? v0[r] * keep_scale : 0.0f;
+          v1[r] = uniform01_u32(seed, i0 + 32u) >= t.drop_p ? v1[r] * keep_scale : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint64_t i0 = first + (uint64_t)((r & 3) + 8 * (r >> 2)) * (uint64_t)cols;
+          v0[r] = dropout_uniform(seed, i0) >= t.drop_p ? v0[r] * keep_scale : 0.0f;
+          v1[r] = dropout_uniform(seed, i0 + 32) >= t.drop_p ? v1[r] * keep_scale : 0.0f;
+        }
+      }
+    }
+    if (t.residual != nullptr) {
+      const float* corner = t.residual + (int64_t)row0 * t.res_ld + col0;
+      const int ld = (int)t.res_ld, off = lrow * ld + lcol;
+      float q0[16], q1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = off + ((r & 3) + 8 * (r >> 2)) * ld;
+        q0[r] = corner[o];
+        q1[r] = corner[o + 32];
+      }
+      if (t.residual_is_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v0[r] = q0[r] > 0.0f ? v0[r] * t.mask_scale : (q0[r] < 0.0f ? v0[r] * t.mask_neg_scale : 0.0f);
+          v1[r] = q1[r] > 0.0f ? v1[r] * t.mask_scale : (q1[r] < 0.0f ? v1[r] * t.mask_neg_scale : 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v0[r] += q0[r];
+          v1[r] += q1[r];
+        }
+      }
+    }
+    float* corner = out + (int64_t)row0 * out_ld + col0;
+    const int ld = (int)out_ld, off = lrow * ld + lcol;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = off + ((r & 3) + 8 * (r >> 2)) * ld;
+      corner[o] = v0[r];
+      corner[o + 32] = v1[r];
+    }
+  }
+
   template <bool RELU>
   __device__ static void store_direct(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
                                       float* __restrict__ out, int64_t out_ld, const Tail& t, float2 bias) {
+    // tiles inside the output whose row offsets fit 32 bits take the short route
+    const bool interior = row0 + BM <= rows && col0 + BN <= cols && t.add_index == nullptr &&
+                          (int64_t)BM * out_ld < (1ll << 30) && (int64_t)BM * t.add_ld < (1ll << 30) &&
+                          (int64_t)BM * t.res_ld < (1ll << 30);
+    if (interior)
+      store_interior<RELU>(acc0, acc1, row0, col0, cols, out, out_ld, t, bias);
+    else
+      store_general<RELU>(acc0, acc1, row0, col0, rows, cols, out, out_ld, t, bias);
+  }
+
+  template <bool RELU>
+  __device__ static void store_general(const f32x16& acc0, const f32x16& acc1, int row0, int col0, int rows, int cols,
+                                       float* __restrict__ out, int64_t out_ld, const Tail& t, float2 bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WN, wc = wave % WN;
     const int lo = lane & 31, hi = lane >> 5;
@@ -499,8 +668,8 @@ struct Core {
         }
         if (drop) {
           const uint64_t base = (uint64_t)gr * (uint64_t)cols;
-          v0 = uniform01(seed, base + (uint64_t)c0) >= t.drop_p ? v0 * keep_scale : 0.0f;
-          v1 = uniform01(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
+          v0 = dropout_uniform(seed, base + (uint64_t)c0) >= t.drop_p ? v0 * keep_scale : 0.0f;
+          v1 = dropout_uniform(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
         }
         if (t.residual != nullptr) {
           if (t.residual_is_mask) {
@@ -535,7 +704,7 @@ struct FwdArgs {
   int32_t M, N;
 };
 
-template <int BM, int BN, int EPI, bool VEC, bool DEEP = false, int PREC = PREC_F32>
+template <int BM, int BN, int EPI, bool VEC, int DEEP = 0, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   using C = Core<BM, BN, true, true, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -648,7 +817,7 @@ struct BwdDataArgs {
   int64_t add_ld;
 };
 
-template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
+template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
   using C = Core<BM, BN, true, false, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -683,7 +852,7 @@ struct WgradArgs {
 // One workgroup's share: the [BM x BN] tile (tile_n, tile_k) of the partial sums of row chunk `chunk`.
 // zero_bias: the chunk's bias slots are cleared instead of filled (a term without a bias gradient that shares
 // its partial buffer with one that has it).
-template <int BM, int BN, bool VEC, bool DEEP, int PREC>
+template <int BM, int BN, bool VEC, int DEEP, int PREC>
 __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int tile_n, int tile_k, int chunk, float* lds,
                                            float (*bsum)[BM], bool zero_bias) {
   using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
@@ -727,7 +896,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int tile_n, int t
   }
 }
 
-template <int BM, int BN, bool VEC, bool DEEP = false, int PREC = PREC_F32>
+template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
   using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -738,6 +907,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
 // Several small weight gradients in one launch: workgroup b belongs to the term whose block range holds b
 // and computes one (tile, chunk) of it exactly as linear_wgrad_kernel would.
 constexpr int kGroupMax = 16;
+constexpr int kGroupChunkRows = 2048;  // rows per chunk of a long term inside a group
 
 struct WgradGroup {
   WgradArgs item[kGroupMax];
@@ -1114,7 +1284,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
     if (relu)
       keep = y[m * y_ld + c] > 0.0f;
     else
-      keep = p <= 0.0f || uniform01(seed, (uint64_t)i) >= p;
+      keep = p <= 0.0f || dropout_uniform(seed, (uint64_t)i) >= p;
     dz[m * dz_ld + c] = keep ? g * scale : 0.0f;
   }
 }
@@ -1211,9 +1381,15 @@ static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t
   const int mask = g_matmul_bf16.load(std::memory_order_relaxed);
   const bool split = (mask & HIVT_BF16_FWD_SPLIT) != 0;
   const bool bf16 = !split && (mask & HIVT_BF16_FWD) != 0;
+  // a reduction of 128 or more: four steps in flight (the whole reduction at 128)
+  const bool deep4 = HIVT_DEPTH4 != 0 && K >= 128;
   // grids that leave compute units with a single workgroup get the deep-prefetch variant
 #define HIVT_FWD_CASE(BM_, BN_, E_)                                                                          \
-  if (vec && split)                                                                                          \
+  if (vec && split && deep4)                                                                                 \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, 2, PREC_SPLIT>), grid, dim3(kThreads), 0, s, a); \
+  else if (vec && bf16 && deep4)                                                                             \
+    hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, 2, PREC_BF16>), grid, dim3(kThreads), 0, s, a); \
+  else if (vec && split)                                                                                     \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, PREC_SPLIT>), grid, dim3(kThreads), 0, s, a); \
   else if (vec && bf16) /* bf16 forward: the deep-prefetch variant wins at every grid size (13-20 % on large ones) */ \
     hipLaunchKernelGGL((linear_fwd_kernel<BM_, BN_, E_, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);  \
@@ -1402,9 +1578,10 @@ int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int6
 // ---------------------------------------------------------------------------------------------
 // Several weight gradients per call.  items: count x 10 int64 -- dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none),
 // flags (bit 0: add to what dw / dbias hold; bit 1: this term joins the item before it: same dw, its sum is
-// added to that item's, no bias term of its own).  Every result equals what hivt_linear_wgrad (or its
-// accumulating form) returns for the item; terms small enough for the grouped kernels share launches (sixteen
-// per launch), the rest go through the single-product path one by one.
+// added to that item's, no bias term of its own).  Terms share launches, sixteen per launch, long chunks
+// first.  A term that hivt_linear_wgrad would cut into fewer than 64 row chunks gets the same chunks and the
+// same order of sums here (bit-identical results); a longer one is summed in chunks of about 2048 rows (equal
+// to rounding).  Terms whose operands do not allow 16-byte loads go through the single-product path one by one.
 // ---------------------------------------------------------------------------------------------
 namespace {
 
@@ -1441,10 +1618,20 @@ int parse_group(const char* what, const int64_t* items, int32_t count, std::vect
     g.chunks = g.M > 0 ? pick_chunks(g.M, g.tiles) : 0;
     g.chunk_rows = g.M > 0 ? (int)(((g.M + g.chunks - 1) / g.chunks + kBK - 1) / kBK * kBK) : 0;
     if (g.M > 0) g.chunks = (int)((g.M + g.chunk_rows - 1) / g.chunk_rows);
+    g.ws_floats = align_up(hivt_linear_wgrad_workspace_bytes(g.M, g.N, g.K), 256) / sizeof(float);
+    if (g.M > 0 && (g.chunks >= 64 || (unsigned)(g.chunks * g.tiles) > kSmallGrid)) {
+      // a long term: on its own it is cut into hundreds of chunks to fill the device; inside a group the other
+      // terms do that, so it takes chunks of kGroupChunkRows rows (fewer partial sums to write and add up)
+      g.chunk_rows = kGroupChunkRows;
+      g.chunks = (int)((g.M + g.chunk_rows - 1) / g.chunk_rows);
+      if (g.chunks > 63) {
+        g.chunk_rows = (int)(((g.M + 62) / 63 + kBK - 1) / kBK * kBK);
+        g.chunks = (int)((g.M + g.chunk_rows - 1) / g.chunk_rows);
+      }
+    }
     const Operand a = make_operand(g.dy, g.dy_ld, g.N, (int32_t)g.M, false);
     const Operand b = make_operand(g.x, g.x_ld, g.K, (int32_t)g.M, false);
-    g.groupable = g.M > 0 && a.vec_ok && b.vec_ok && g.chunks < 64 && (unsigned)(g.chunks * g.tiles) <= kSmallGrid;
-    g.ws_floats = align_up(hivt_linear_wgrad_workspace_bytes(g.M, g.N, g.K), 256) / sizeof(float);
+    g.groupable = g.M > 0 && a.vec_ok && b.vec_ok;
   }
   // an entry (an item and the one that joins it) goes through the grouped kernels only as a whole
   for (int32_t i = 0; i < count; ++i)
@@ -1499,9 +1686,15 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
       hipLaunchKernelGGL((linear_wgrad_group_kernel<64, 128, PREC_F32>), dim3(blocks), dim3(kThreads), 0, s, wg);
     wg = WgradGroup{};
   };
-  for (int32_t i = 0; i < count; ++i) {
+  // launch order: long chunks first, so that workgroups of similar duration share a launch (a launch lasts as
+  // long as its longest workgroup); a joining term stays behind its item
+  std::vector<int32_t> order;
+  for (int32_t i = 0; i < count; ++i)
+    if (g[(size_t)i].groupable && !g[(size_t)i].joins) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return g[(size_t)a].chunk_rows > g[(size_t)b].chunk_rows; });
+  auto add_product = [&](int32_t i) {
     const GroupItem& it = g[(size_t)i];
-    if (!it.groupable) continue;
     // a joining term lays its chunks out like the item it joins (bias slots included, cleared)
     const GroupItem& head = it.joins ? g[(size_t)i - 1] : it;
     const int64_t pitch = (int64_t)head.N * head.K + (head.dbias ? head.N : 0);
@@ -1517,6 +1710,10 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
     wg.zero_bias[wg.count] = it.joins ? 1 : 0;
     wg.first_block[wg.count + 1] = wg.first_block[wg.count] + it.tiles * it.chunks;
     if (++wg.count == kGroupMax) flush_products();
+  };
+  for (int32_t i : order) {
+    add_product(i);
+    if (i + 1 < count && g[(size_t)i + 1].joins) add_product(i + 1);
   }
   flush_products();
   HIVT_CHECK_LAUNCH(what);

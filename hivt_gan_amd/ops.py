@@ -597,12 +597,12 @@ def _launch_wgrad_group(flat, count: int, dev) -> None:
 
 
 # Weight gradients are leaves of the backward pass: nothing but the optimizer reads them.  Inside
-# ``deferred_weight_grads()`` the products of layers with at most ``_DEFER_MAX_ROWS`` rows (a launch each for
-# the product and for the sum over its chunks, all latency at that size) are collected while the backward pass
-# runs and issued together when it ends (a callback of the autograd engine), a few launches for all of them.
+# ``deferred_weight_grads()`` their products (on their own a launch each for the product and for the sum over
+# its chunks: all latency for layers of a few thousand rows, ramp-up and partial-sum traffic for long ones) are
+# collected while the backward pass runs and issued together when it ends (a callback of the autograd engine),
+# a few launches for all of them.  The operands stay alive until then.
 # The gradient tensors handed to autograd exist from the start and are filled by that call; nothing may read
 # a parameter's ``.grad`` from a hook before the pass has ended.
-_DEFER_MAX_ROWS = 8192
 _deferred: Optional[list] = None
 
 
@@ -652,7 +652,7 @@ def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int,
     ``leaves``: weight and bias are leaves of the graph, so the product may be deferred."""
     dw = torch.empty(n, k, dtype=torch.float32, device=dev)
     db = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
-    if leaves and _deferred is not None and 0 < m <= _DEFER_MAX_ROWS:
+    if leaves and _deferred is not None and m > 0:
         if not _deferred:
             torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
         # addresses, not tensors, of the results: autograd takes a gradient over only while it holds the one

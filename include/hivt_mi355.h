@@ -294,9 +294,10 @@ int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_
  * where a launch per product and per sum is all latency).  `items` holds `count` rows of ten int64:
  *   dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none), flags
  * flags bit 0: the sums are added to what dw / dbias hold; bit 1: the term joins the item before it (same dw,
- * N, K; its sum is added to that item's; no bias term).  Every result is bit-identical to hivt_linear_wgrad on
- * the same item (torch.nn.Linear's weight.grad / bias.grad, as `loss.backward()` fills them in
- * models/hivt.py:283,312,325).  Terms of fewer than 64 row chunks share launches, sixteen terms per launch. */
+ * N, K; its sum is added to that item's; no bias term).  Results are those of hivt_linear_wgrad on the same
+ * item (torch.nn.Linear's weight.grad / bias.grad, as `loss.backward()` fills them in
+ * models/hivt.py:283,312,325): bit-identical for terms that call cuts into fewer than 64 row chunks, equal to
+ * rounding for longer ones (summed in chunks of about 2048 rows).  Sixteen terms per launch. */
 size_t hivt_linear_wgrad_group_workspace_bytes(const int64_t* items, int32_t count);
 int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void* workspace, size_t workspace_bytes,
                             hivt_stream_t stream);

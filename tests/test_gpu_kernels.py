@@ -653,7 +653,15 @@ def test_fused_linear_dropout_and_residual_epilogue(relu):
     if res is not None:
         ref = ref + res
     want = torch.autograd.grad(ref, inputs, go)
-    for a, b in zip(got, want):
+    # where the pre-dropout value is numerically zero the output does not show whether the element was dropped;
+    # rows of x and rows of W / entries of b that such an element feeds are left out of the comparison
+    unsure = ~live & (pre != 0) if relu else ~live  # an exact zero behind the ReLU passes no gradient either way
+    rows_ok, cols_ok = ~unsure.any(dim=1), ~unsure.any(dim=0)
+    assert int(rows_ok.sum()) > M - 8 and int(cols_ok.sum()) > N - 8
+    close(got[0][rows_ok], want[0][rows_ok], 1e-4, atol=2e-5)
+    close(got[1][cols_ok], want[1][cols_ok], 1e-4, atol=2e-5)
+    close(got[2][cols_ok], want[2][cols_ok], 1e-4, atol=2e-5)
+    for a, b in zip(got[3:], want[3:]):
         close(a, b, 1e-4, atol=2e-5)
     # evaluation mode: no dropout
     y_eval = ops.fused_linear(x, lin.weight, lin.bias, relu=relu, dropout_p=p, training=False, residual=res)

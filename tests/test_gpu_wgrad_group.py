@@ -34,7 +34,7 @@ def test_group_equals_single_calls_bit_for_bit(precision):
 
         shapes = [(2615, 128, 128, True), (2615, 512, 128, True), (2615, 128, 512, True), (2615, 1, 256, True),
                   (2615, 256, 60, False), (700, 384, 128, True), (2615, 256, 30, True),  # K = 30: no vector loads
-                  (40000, 128, 128, True),  # too many row chunks for the grouped kernels
+                  (40000, 128, 128, True),  # a long term: coarser chunks inside a group
                   (1, 64, 64, True)] + [(2615, 128, 128, True)] * 12  # more than sixteen terms: two launches
         terms, want = [], []
         for m, n, k, bias in shapes:
@@ -58,6 +58,11 @@ def test_group_equals_single_calls_bit_for_bit(precision):
         ops.linear_wgrad_group(terms)
         torch.cuda.synchronize()
         for (m, n, k, bias), (_, _, dw, db, _, _), (ref_w, ref_b) in zip(shapes, terms, want):
+            if m >= 16384:  # a long term is summed in other chunks than the single call's: equal to rounding
+                tol = 2e-2 if precision == "bf16" else 1e-5
+                assert float((dw - ref_w).abs().max()) <= tol * float(ref_w.abs().max()), (m, n, k)
+                assert float((db - ref_b).abs().max()) <= 1e-5 * float(ref_b.abs().max()), (m, n, k)
+                continue
             assert torch.equal(dw, ref_w), (m, n, k)
             if bias:
                 assert torch.equal(db, ref_b), (m, n, k)

@@ -15,15 +15,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hivt_gan_amd import _lib  # noqa: E402  (argument types of hivt_linear_fwd)
 
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, "probe", "libhivt_probe.so"))
+lib = ctypes.CDLL(os.environ.get("PROBE_LIB", os.path.join(here, "probe", "libhivt_probe.so")))
 lib.hivt_linear_fwd.restype = ctypes.c_int
 lib.hivt_linear_fwd.argtypes = _lib.SIGNATURES["hivt_linear_fwd"][1]
 lib.hivt_probe_set.argtypes = [ctypes.c_void_p]
 
 dev = "cuda:0"
 torch.manual_seed(0)
+if os.environ.get("PROBE_BF16"):  # operand-precision mask of the products (14 = the library's bf16 mode)
+    lib.hivt_set_matmul_bf16.argtypes = [ctypes.c_int]
+    lib.hivt_set_matmul_bf16(int(os.environ["PROBE_BF16"]))
 PAD = int(os.environ.get("PROBE_PAD", "0"))  # extra floats per row of x and w (breaks power-of-two strides)
 shapes = [(136_000, 128, 256), (136_000, 128, 128), (55_000, 512, 128), (2623, 128, 128), (2623, 512, 256)]
+if os.environ.get("PROBE_SMALL"):
+    shapes = [(2623, 128, 128), (2623, 128, 256), (2623, 256, 256), (2623, 128, 512), (2623, 512, 128)]
 for (M, K, N) in shapes:
     x = torch.randn(M, K + PAD, device=dev)
     w = torch.randn(N, K + PAD, device=dev)
