@@ -34,6 +34,11 @@ struct SegAttnArgs {
   const int32_t* rowptr;
   int32_t N;
   int32_t H;
+  // 0: edge e of the CSR order is row e of k / v / dk / dv.  Otherwise the rows of a target are interleaved
+  // ("step-major": the j-th edge of target n is row j * row_interleave + n), the layout of a [steps, targets,
+  // width] tensor whose targets attend over their own steps.
+  int32_t row_interleave;
+  int32_t seg_len;  // with row_interleave: rows per target in k / v (E / N); a target reads no more than that
   float scale_inv;
   float dropout_p;
   uint64_t seed;
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   const int nc = row_ok ? n : a.N - 1;
 
   const int beg = a.rowptr[nc];
-  const int end = row_ok ? a.rowptr[nc + 1] : beg;
+  int end = row_ok ? a.rowptr[nc + 1] : beg;
+  if (a.row_interleave) end = min(end, beg + a.seg_len);
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (end > beg) {  // rows without edges never need their query
     qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
@@ -141,8 +147,9 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
       const int e = e0 + u * STRIDE;
       ok[u] = e < end;
       const int64_t ee = ok[u] ? e : e0;
-      kk[u] = ldg4(a.k + ee * a.kv_stride + 4 * c);
-      vv[u] = ldg4(a.v + ee * a.kv_stride + 4 * c);
+      const int64_t er = a.row_interleave ? (ee - beg) * a.row_interleave + nc : ee;
+      kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
+      vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
       if (GLOBAL) {
         const int64_t j = a.src[ee];
         kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
@@ -235,7 +242,8 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   const int nc = row_ok ? n : a.N - 1;
 
   const int beg = a.rowptr[nc];
-  const int end = row_ok ? a.rowptr[nc + 1] : beg;
+  int end = row_ok ? a.rowptr[nc + 1] : beg;
+  if (a.row_interleave) end = min(end, beg + a.seg_len);
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs;
   float delta = 0.0f, mh = 0.0f, inv_den = 0.0f;
   if (end > beg) {
@@ -263,8 +271,9 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
       const int e = e0 + u * STRIDE;
       ok[u] = e < end;
       const int64_t ee = ok[u] ? e : e0;
-      kk[u] = ldg4(a.k + ee * a.kv_stride + 4 * c);
-      vv[u] = ldg4(a.v + ee * a.kv_stride + 4 * c);
+      const int64_t er = a.row_interleave ? (ee - beg) * a.row_interleave + nc : ee;
+      kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
+      vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
       if (GLOBAL) {
         const int64_t j = a.src[ee];
         kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
@@ -285,9 +294,10 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
         }
         const float am = alpha * ms;
         const float ds = alpha * (dav * ms - delta);
-        *reinterpret_cast<float4*>(a.dv + e * a.dkv_stride + 4 * c) =
+        const int64_t er = a.row_interleave ? (e - beg) * a.row_interleave + nc : e;
+        *reinterpret_cast<float4*>(a.dv + er * a.dkv_stride + 4 * c) =
             make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
-        *reinterpret_cast<float4*>(a.dk + e * a.dkv_stride + 4 * c) =
+        *reinterpret_cast<float4*>(a.dk + er * a.dkv_stride + 4 * c) =
             make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
         fma4(dq, ds, kk[u]);
       }
@@ -481,6 +491,11 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
+  if (dtype & HIVT_ROWS_INTERLEAVED) {
+    HIVT_REQUIRE(!global && E % N == 0, HIVT_ERR_ARG,
+                 "%s: interleaved rows need E a multiple of N and no node terms (E=%lld N=%d)", what, (long long)E, N);
+    a.row_interleave = N; a.seg_len = (int32_t)(E / N);
+  }
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
   a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = out; a.m = m_out; a.den = den_out;
@@ -532,6 +547,12 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
   a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
+  if (dtype & HIVT_ROWS_INTERLEAVED) {
+    HIVT_REQUIRE(!global && E % N == 0 && !zero_tail, HIVT_ERR_ARG,
+                 "%s: interleaved rows need E a multiple of N, no node terms and no padding (E=%lld N=%d)", what,
+                 (long long)E, N);
+    a.row_interleave = N; a.seg_len = (int32_t)(E / N);
+  }
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
   a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);

@@ -16,7 +16,7 @@ for row, of its per-timestep loop (``:73-78``).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -393,14 +393,36 @@ class TemporalEncoderLayer(nn.Module):
             y = F.dropout(y, kw.get("dropout_p", 0.0), kw.get("training", False))
             return y if kw.get("residual") is None else kw["residual"] + y
 
-        q = lin(xn[-1], w[:D], b[:D]).view(1, N, H, hd)
-        kv = lin(xn, w[D:], b[D:]).view(S, N, 2, H, hd)
-        scores = (kv[:, :, 0] * q).sum(dim=-1) * (hd ** -0.5)             # [S, N, H]
-        prob = F.dropout(torch.softmax(scores, dim=0), mha.dropout, self.training)
-        o = (prob.unsqueeze(-1) * kv[:, :, 1]).sum(dim=0).reshape(N, D)
+        if gpu and N > 0 and ops.seg_attn_supported(D, H):
+            # one query per agent over its own S steps: the segment-attention kernel on the [S, N, 2D] keys and
+            # values as they lie (the j-th "edge" of agent n is row j * N + n)
+            q = lin(xn[-1], w[:D], b[:D])
+            kv = lin(xn, w[D:], b[D:]).view(S * N, 2 * D)
+            o = ops.seg_attn(q, kv, _step_rowptr(N, S, src.device), H, mha.dropout, self.training, interleaved=True,
+                             tag=type(self).__name__)
+        else:
+            q = lin(xn[-1], w[:D], b[:D]).view(1, N, H, hd)
+            kv = lin(xn, w[D:], b[D:]).view(S, N, 2, H, hd)
+            scores = (kv[:, :, 0] * q).sum(dim=-1) * (hd ** -0.5)             # [S, N, H]
+            prob = F.dropout(torch.softmax(scores, dim=0), mha.dropout, self.training)
+            o = (prob.unsqueeze(-1) * kv[:, :, 1]).sum(dim=0).reshape(N, D)
         x = lin(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p, training=self.training,
                 residual=src[-1])
         return self._ff_residual(x)
+
+
+_step_rowptrs: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def _step_rowptr(n: int, steps: int, device: torch.device) -> torch.Tensor:
+    """``[0, steps, 2 steps, ..]`` (int32, n + 1 entries): every target owns ``steps`` rows."""
+    key = (n, steps, str(device))
+    t = _step_rowptrs.get(key)
+    if t is None:
+        if len(_step_rowptrs) > 64:
+            _step_rowptrs.clear()
+        t = _step_rowptrs[key] = (torch.arange(n + 1, dtype=torch.int64) * steps).to(torch.int32).to(device)
+    return t
 
 
 class _EncoderStack(nn.Module):

@@ -363,7 +363,7 @@ class _SegAttn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed, tag,
-                padded):
+                padded, interleaved=False):
         _need_gpu(q, kv, rowptr)
         n, d_model = q.shape
         e = kv.shape[0]
@@ -386,17 +386,17 @@ class _SegAttn(torch.autograd.Function):
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
                     _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(out),
-                    _p(m), _p(den), 0, _stream(q))
+                    _p(m), _p(den), ROWS_INTERLEAVED if interleaved else 0, _stream(q))
         ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den,
                               DEVICE_SEED if dropout_p > 0.0 else None)
-        ctx.cfg = (num_heads, float(dropout_p), int(seed), tag, bool(padded))
+        ctx.cfg = (num_heads, float(dropout_p), int(seed), tag, bool(padded), bool(interleaved))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out):
         q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den, seed_dev = ctx.saved_tensors
-        num_heads, dropout_p, seed, tag, padded = ctx.cfg
+        num_heads, dropout_p, seed, tag, padded, interleaved = ctx.cfg
         n, d_model = q.shape
         e = kv.shape[0]
         d_out = d_out.contiguous()
@@ -408,33 +408,48 @@ class _SegAttn(torch.autograd.Function):
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
                   _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
-                  _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, 0, _stream(q))
+                  _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, ROWS_INTERLEAVED if interleaved else 0,
+                  _stream(q))
         dkv_node = None
         if kv_node is not None and ctx.needs_input_grad[2]:
             ns = kv_node.shape[0]
             dkv_node = torch.empty(ns, 2 * d_model, dtype=torch.float32, device=q.device)
             _lib.call("hivt_segment_sum_rows", _p(dkv), 2 * d_model, 2 * d_model, _p(rowptr_by_src), _p(perm_by_src),
                       ns, _p(dkv_node), 2 * d_model, _stream(q))
-        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None, None
+        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None, None, None
+
+
+ROWS_INTERLEAVED = 1 << 16  # layout flag in the dtype argument of hivt_seg_attn_fwd / _bwd
+
+
+def seg_attn_supported(d_model: int, num_heads: int) -> bool:
+    """Widths the segment-attention kernels are built for."""
+    if d_model not in (16, 32, 64, 128, 256) or num_heads <= 0 or d_model % (4 * num_heads) != 0:
+        return False
+    return d_model // num_heads in (4, 8, 16, 32)
 
 
 def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
              training: bool = False, kv_node: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
              rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None,
-             tag: str = "", padded: bool = False) -> torch.Tensor:
+             tag: str = "", padded: bool = False, interleaved: bool = False) -> torch.Tensor:
     """Segment-softmax attention over CSR rows.
 
     ``q`` [N,D]; ``kv`` [E,2D] holds K | V per edge in CSR order; optional ``kv_node`` [Ns,2D] adds the
     source node's K | V (``src`` gives the source id of every CSR-ordered edge, and the CSR over
     sources is needed for its gradient).  ``padded`` says that ``kv`` has more rows than ``rowptr``
     covers (fixed-capacity edge lists): the gradient rows of that padding are then zeroed.
+    ``interleaved``: every target has E / N edges and the j-th edge of target n is row ``j * N + n`` of ``kv``
+    (a [steps, N, 2D] tensor whose targets attend over their own steps); no node terms, no padding.
     Returns the aggregated messages [N,D]."""
     p = float(dropout_p) if training else 0.0
     seed = _fresh_seed() if p > 0.0 else 0
     if kv_node is not None and kv_node.requires_grad and (rowptr_by_src is None or perm_by_src is None):
         raise ValueError("gradient of the node terms needs the CSR over sources")
+    if interleaved and (kv_node is not None or padded or q.shape[0] == 0 or kv.shape[0] % q.shape[0] != 0):
+        raise ValueError("interleaved rows: E must be a multiple of N, without node terms or padding")
     return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed, tag,
-                          padded)
+                          padded, bool(interleaved))
 
 
 # --------------------------------------------------------------------------------------------

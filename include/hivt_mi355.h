@@ -159,6 +159,13 @@ int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angl
  * Kernels (b)+(c): per-edge QK dot, segment softmax over CSR rows, weighted sum of V
  * ------------------------------------------------------------------------------------------ */
 
+/* Layout flag of the `dtype` argument of hivt_seg_attn_fwd / hivt_seg_attn_bwd (bit 16): the rows of k, v, dk and
+ * dv are interleaved -- the j-th edge of target n is row j * N + n, every target has E / N rows.  That is a
+ * [steps, targets, width] tensor whose targets attend over their own steps: the last position of the temporal
+ * encoder's final layer, which is all the encoder's caller reads of it (models/local_encoder.py:241).  No node
+ * terms and no padded tail in this layout. */
+#define HIVT_ROWS_INTERLEAVED (1 << 16)
+
 /* out[n,h,:] = sum_{e in row n} drop(softmax_e(q[n,h,:] . key_e[h,:] / sqrt(D/H))) * val_e[h,:]
  * with key_e = k[e] (+ k_node[src[e]] when k_node != NULL), val_e likewise; softmax is
  * exp(s - max) / (sum + 1e-16) per (row, head) exactly as torch_geometric.utils.softmax; rows

@@ -928,3 +928,33 @@ def test_unsupported_gpu_shapes_raise_instead_of_falling_back():
     with pytest.raises(ops.UnsupportedShapeError):
         layer._sa_block(torch.randn(40, 3, 64, device=DEV), torch.randn(40, 3, 64, device=DEV))
     assert ops.fused_linear(x, lin.weight, lin.bias).shape == (10, 256)  # the plain product has no width limit
+
+
+@pytest.mark.parametrize("steps,n,d,h", [(21, 300, 128, 8), (5, 70, 64, 8), (1, 9, 16, 2)])
+def test_seg_attn_over_interleaved_rows(steps, n, d, h):
+    """Every target attends over its own `steps` rows of a [steps, N, 2D] tensor (row j * N + n): values and
+    gradients against the softmax written out with framework ops, and against the same call on the rows
+    re-laid in CSR order."""
+    gen = torch.Generator().manual_seed(steps * 1000 + n)
+    q = torch.randn(n, d, generator=gen).to(DEV).requires_grad_(True)
+    kv = torch.randn(steps, n, 2 * d, generator=gen).to(DEV).requires_grad_(True)
+    go = torch.randn(n, d, generator=gen).to(DEV)
+    rowptr = (torch.arange(n + 1) * steps).to(torch.int32).to(DEV)
+    out = ops.seg_attn(q, kv.view(steps * n, 2 * d), rowptr, h, interleaved=True)
+    got = torch.autograd.grad(out, (q, kv), go)
+    hd = d // h
+    k, v = kv[..., :d].reshape(steps, n, h, hd), kv[..., d:].reshape(steps, n, h, hd)
+    scores = (k * q.view(1, n, h, hd)).sum(-1) * hd ** -0.5
+    ref = (torch.softmax(scores, dim=0).unsqueeze(-1) * v).sum(0).reshape(n, d)
+    want = torch.autograd.grad(ref, (q, kv), go)
+    close(out, ref, 1e-5, atol=1e-6)
+    for a, b in zip(got, want):
+        close(a, b, 1e-5, atol=1e-6)
+    # the same edges in CSR order (target-major rows): identical sums, so identical bits
+    kv_csr = kv.detach().transpose(0, 1).reshape(n * steps, 2 * d).contiguous().requires_grad_(True)
+    out_csr = ops.seg_attn(q, kv_csr, rowptr, h)
+    assert torch.equal(out_csr, out)
+    g_csr = torch.autograd.grad(out_csr, kv_csr, go)[0].view(n, steps, 2 * d).transpose(0, 1)
+    assert torch.equal(g_csr, got[1])
+    with pytest.raises(ValueError):
+        ops.seg_attn(q, kv.view(steps * n, 2 * d)[:-1], rowptr, h, interleaved=True)
