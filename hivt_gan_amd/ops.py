@@ -1592,7 +1592,9 @@ class _MaskedStepTokens(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mask, token):
-        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x)
+        # a transposed mask view would hand its permuted layout to the result (and a copy to whoever reshapes it)
+        mask = mask.contiguous()
+        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x.contiguous())
         ctx.save_for_backward(mask)
         return out
 
