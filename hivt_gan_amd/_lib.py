@@ -79,6 +79,9 @@ SIGNATURES = {
                                 _P, _P, _P]),
     "hivt_critic_bwd": (c_int, [_P, _P, _P, c_int64, c_int64, c_int32, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
                                 c_size_t, _P]),
+    "hivt_critics_fwd": (c_int, [_P, c_int32, c_float, c_float, _P, _P]),
+    "hivt_critics_bwd_workspace_bytes": (c_size_t, [_P, c_int32]),
+    "hivt_critics_bwd": (c_int, [_P, c_int32, c_float, c_float, _P, c_size_t, _P]),
     "hivt_hinge_r1_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_hinge_r1_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P]),
     "hivt_weighted_mean_fwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),

@@ -12,6 +12,7 @@ the same arithmetic runs on framework ops.
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -156,3 +157,50 @@ class LongScaleCritic(_HorizonCritic):
 
     def __init__(self, horizon: int, input_dim: int = 2, hidden_dim: int = 256) -> None:
         super().__init__(horizon, input_dim, hidden_dim)
+
+
+def scores_multi(jobs):
+    """``jobs``: ``(critic, trajectories [B, T, D], with_input_grad_norm)`` -- several critic evaluations on GPU
+    tensors as ONE library call (``ops.critic_scores_multi``), with the spectral normalisation of all critics of a
+    round in one launch.  A critic that appears k times goes through k power iterations in the order of its
+    jobs, as k calls of its ``forward`` would.  Returns per job ``scores`` or ``(scores, grad_norm2)``."""
+    rounds, seen = [], {}
+    for idx, (critic, _, _) in enumerate(jobs):
+        k = seen.get(id(critic), 0)
+        seen[id(critic)] = k + 1
+        while len(rounds) <= k:
+            rounds.append([])
+        rounds[k].append(idx)
+    weights_of = {}
+    for members in rounds:
+        layers = [(idx, m) for idx in members for m in jobs[idx][0]._spectral_layers()]
+        training = jobs[members[0]][0].training
+        for start in range(0, len(layers), 16):
+            part = layers[start:start + 16]
+            ws = ops.spectral_normalize([m.weight_orig for _, m in part], [m.weight_u for _, m in part],
+                                        [m.weight_v for _, m in part], training, _EPS)
+            for (idx, _), w in zip(part, ws):
+                weights_of.setdefault(idx, []).append(w)
+    passes = []
+    for idx, (critic, traj, with_r1) in enumerate(jobs):
+        horizon = getattr(critic, "horizon", None)
+        x = traj if horizon is None else traj[:, :horizon]
+        passes.append((x, weights_of[idx], [m.bias for m in critic._spectral_layers()], with_r1))
+    first = jobs[0][0]
+    slope, drop = first._activation()
+    return ops.critic_scores_multi(passes, slope, drop, first.training)
+
+
+# the critics' passes of a loss term as one library call (False: one call per critic and pass)
+MULTI = os.environ.get("HIVT_CRITICS_MULTI", "1") != "0"
+
+
+def multi_supported(critics, *tensors) -> bool:
+    """Whether ``scores_multi`` applies: GPU tensors, plain trajectory critics that share the activation slope,
+    the dropout rate and the training mode."""
+    critics = list(critics)
+    if not MULTI or not critics or not all(t.is_cuda for t in tensors):
+        return False
+    if not all(isinstance(c, BaseTrajectoryCritic) for c in critics):
+        return False
+    return len({(c._activation(), c.training) for c in critics}) == 1

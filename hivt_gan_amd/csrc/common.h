@@ -57,6 +57,9 @@ inline void zero_words(void* p, int64_t words, hipStream_t stream) {
 }
 
 // out[c] = sum over r < rows of partial[r * cols + c], summed in a fixed order (deterministic).
+// the operand-precision mask set through hivt_set_matmul_bf16()
+int matmul_bf16_mask();
+
 // out[c] (+)= sum over rows of partial[row][c], rows summed in a fixed order
 void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream,
                      bool accumulate = false);

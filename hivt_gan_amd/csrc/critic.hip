@@ -14,9 +14,11 @@
 // whose gradient with respect to the weights is a second chain of the same shape:
 //     e_0 = d r / d g_0,   dW_l += G_l^T e_{l-1},   e_l = (e_{l-1} W_l^T) * c_l,   dw_o += colsum(e_L).
 // All products run on the fp32-MFMA linear kernels of this library.
-#include "common.h"
+#include "linear_core.h"
 
 #include <math.h>
+
+#include <vector>
 
 namespace hivt {
 namespace {
@@ -253,6 +255,242 @@ __global__ __launch_bounds__(256) void weighted_mean_bwd_kernel(const float* __r
   if (i < B) g_s[i] = scale * *g_out * w[i] / *count;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Layer chains.  A critic pass over a few thousand rows is a chain of small products in which every row
+// depends on its own row of the layer before only.  One workgroup therefore carries kChainRows rows of a pass
+// through ALL layers of a chain (the layer outputs go to global memory as the backward pass needs them anyway,
+// and come back through L2), and the workgroups of up to kChainPasses passes -- the real and the generated
+// trajectories of all critics -- share the launch: one launch where the layer-by-layer route issues a dozen
+// per pass, each of them a few microseconds of latency for microseconds of work.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChainPasses = 6;
+constexpr int kChainLayers = 4;   // hidden layers a chain is built for (the reference's critics have 2, 3, 4)
+constexpr int kChainRows = 64;
+
+struct ChainPass {
+  const float* x;
+  int64_t x_ld;
+  int32_t B, L;
+  int32_t w[kChainLayers + 1];
+  const float* weight[kChainLayers + 1];  // weight[l - 1] = W_l [w_l, w_{l-1}]; weight[L] = w_o [1, w_L]
+  const float* bias[kChainLayers + 1];    // forward only
+  float* saved;                           // h_1..h_L, then G_1..G_L and g_0 (laid out as make_shape says)
+  int64_t h_off[kChainLayers + 1], g_off[kChainLayers + 1], g0_off;  // float offsets inside `saved`
+  uint64_t seed;
+  float* scores;                          // forward
+  float* grad_norm2;                      // forward: non-null = the input-gradient chain runs too
+  const float* g_scores;                  // backward (either may be null)
+  const float* g_norm2;
+  float* dz[kChainLayers + 1];            // backward: dz[l] [B, w_l], l = 1..L
+  float* e[kChainLayers + 1];             // backward: e[l] [B, w_l], l = 0..L
+  float* dx;                              // backward, optional
+};
+
+struct ChainArgs {
+  ChainPass pass[kChainPasses];
+  int32_t first_block[kChainPasses + 1];
+  int32_t count;
+  float neg_slope, dropout_p;
+  const uint64_t* seed_ptr;
+};
+
+__device__ __forceinline__ int64_t chain_align(int64_t v) { return (v + 63) / 64 * 64; }
+
+// Writes of this workgroup to global memory become visible to all of its waves: the barrier carries a
+// workgroup-scope release / acquire (the waves of a workgroup share their compute unit's vector cache), which is
+// all a chain needs; a device-scope fence here would flush and invalidate caches a dozen times per workgroup.
+__device__ __forceinline__ void chain_sync() { __syncthreads(); }
+
+// out[rows of the tile][N] = in[.., K] W[N, K]^T, then either Dropout(LeakyReLU(. + bias)) (gate == null) or the
+// gate of the backward chains (no bias)
+template <int PREC>
+__device__ __forceinline__ void chain_fwd_layer(const float* in, int64_t in_ld, const float* W, int K, int N, int B, int row0,
+                                            const float* bias, float neg_slope, float drop_p, uint64_t seed,
+                                            const uint64_t* seed_ptr, const float* gate, float pos_scale,
+                                            float neg_scale, float* out, float* lds) {
+  using C = Core<kChainRows, 128, true, true, true, false, 1, PREC>;
+  Operand a, b;
+  a.p = in; a.ld = in_ld; a.rows = B; a.red = K; a.vec_ok = 1;
+  b.p = W; b.ld = K; b.rows = N; b.red = K; b.vec_ok = 1;
+  Tail t;
+  if (gate != nullptr) {
+    t.residual = gate;
+    t.res_ld = N;
+    t.residual_is_mask = true;
+    t.mask_scale = pos_scale;
+    t.mask_neg_scale = neg_scale;
+  } else {
+    t.bias = bias;
+    t.neg_slope = neg_slope;
+    t.drop_p = drop_p;
+    t.seed = seed;
+    t.seed_ptr = seed_ptr;
+  }
+  for (int col0 = 0; col0 < N; col0 += 128) {
+    f32x16 acc0, acc1;
+    const float2 bias2 = C::bias_pair(t, col0, N);
+    C::accumulate(a, b, row0, col0, 0, K, lds, acc0, acc1);
+    C::template store_direct<false>(acc0, acc1, row0, col0, B, N, out, N, t, bias2);
+  }
+}
+
+// out[rows of the tile][K] = (in[.., N] W[N, K]) gated by `gate` (null: no gate)
+template <int PREC>
+__device__ __forceinline__ void chain_bwd_layer(const float* in, int N, const float* W, int K, int B, int row0,
+                                            const float* gate, float pos_scale, float neg_scale, float* out,
+                                            float* lds) {
+  using C = Core<kChainRows, 128, true, false, true, false, 1, PREC>;
+  Operand a, b;
+  a.p = in; a.ld = N; a.rows = B; a.red = N; a.vec_ok = 1;
+  b.p = W; b.ld = K; b.rows = K; b.red = N; b.vec_ok = 1;
+  Tail t;
+  if (gate != nullptr) {
+    t.residual = gate;
+    t.res_ld = K;
+    t.residual_is_mask = true;
+    t.mask_scale = pos_scale;
+    t.mask_neg_scale = neg_scale;
+  }
+  for (int col0 = 0; col0 < K; col0 += 128) {
+    f32x16 acc0, acc1;
+    C::accumulate(a, b, row0, col0, 0, N, lds, acc0, acc1);
+    C::template store_direct<false>(acc0, acc1, row0, col0, B, K, out, K, t, make_float2(0.0f, 0.0f));
+  }
+}
+
+// out[r][c] = (row ? row[r] : 1) * vec[c] * act_factor(h[r][c]) for the tile's rows
+__device__ __forceinline__ void chain_gate_init(const float* row, const float* vec, const float* h, int W, int B,
+                                                int row0, float keep_scale, float neg_slope, float* out) {
+  for (int i = threadIdx.x; i < kChainRows * W; i += kThreads) {
+    const int r = row0 + i / W, c = i % W;
+    if (r >= B) break;
+    const int64_t at = (int64_t)r * W + c;
+    float v = act_factor(h[at], keep_scale, neg_slope) * vec[c];
+    if (row != nullptr) v *= row[r];
+    out[at] = v;
+  }
+}
+
+template <int PF, int PD>
+__global__ __launch_bounds__(kThreads) void critic_chain_kernel(const ChainArgs g, int backward) {
+  using CF = Core<kChainRows, 128, true, true, true, false, 1, PF>;
+  using CD = Core<kChainRows, 128, true, false, true, false, 1, PD>;
+  constexpr int LDS = CF::LDS_FLOATS > CD::LDS_FLOATS ? CF::LDS_FLOATS : CD::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDS];
+  int pi = 0;
+  while (pi + 1 < g.count && g.first_block[pi + 1] <= (int)blockIdx.x) ++pi;
+  const ChainPass& p = g.pass[pi];
+  const int row0 = ((int)blockIdx.x - g.first_block[pi]) * kChainRows;
+  const int B = p.B, L = p.L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float keep_scale = 1.0f / (1.0f - g.dropout_p);
+  const float* w_o = p.weight[L];
+
+  if (!backward) {
+    const float* in = p.x;
+    int64_t in_ld = p.x_ld;
+    for (int l = 1; l <= L; ++l) {  // h_l = Dropout(LeakyReLU(h_{l-1} W_l^T + b_l)); every layer draws its own stream
+      float* h = p.saved + p.h_off[l];
+      chain_fwd_layer<PF>(in, in_ld, p.weight[l - 1], p.w[l - 1], p.w[l], B, row0, p.bias[l - 1], g.neg_slope, g.dropout_p,
+                          p.seed + 0x51ED27ull * (uint64_t)l, g.seed_ptr, nullptr, 0.0f, 0.0f, h, lds);
+      chain_sync();
+      in = h;
+      in_ld = p.w[l];
+    }
+    // D = h_L . w_o + b_o: a wave per row
+    const int WL = p.w[L];
+    const float b_o = p.bias[L][0];
+    for (int r = row0 + wave; r < min(B, row0 + kChainRows); r += kThreads / 64) {
+      float s = 0.0f;
+      for (int c = lane; c < WL; c += 64) s += in[(int64_t)r * WL + c] * w_o[c];
+      s = wave_sum(s);
+      if (lane == 0) p.scores[r] = s + b_o;
+    }
+    if (p.grad_norm2 == nullptr) return;
+    // input gradient: G_L = w_o * c_L, g_{l-1} = G_l W_l, G_{l-1} = g_{l-1} * c_{l-1}
+    chain_gate_init(nullptr, w_o, p.saved + p.h_off[L], WL, B, row0, keep_scale, g.neg_slope, p.saved + p.g_off[L]);
+    chain_sync();
+    for (int l = L; l >= 1; --l) {
+      float* out = l > 1 ? p.saved + p.g_off[l - 1] : p.saved + p.g0_off;
+      chain_bwd_layer<PD>(p.saved + p.g_off[l], p.w[l], p.weight[l - 1], p.w[l - 1], B, row0,
+                          l > 1 ? p.saved + p.h_off[l - 1] : nullptr, keep_scale, keep_scale * g.neg_slope, out, lds);
+      chain_sync();
+    }
+    const int W0 = p.w[0];
+    const float* g0 = p.saved + p.g0_off;
+    for (int r = row0 + wave; r < min(B, row0 + kChainRows); r += kThreads / 64) {
+      float s = 0.0f;
+      for (int c = lane; c < W0; c += 64) {
+        const float v = g0[(int64_t)r * W0 + c];
+        s += v * v;
+      }
+      s = wave_sum(s);
+      if (lane == 0) p.grad_norm2[r] = s;
+    }
+    return;
+  }
+
+  // ---- backward ----
+  if (p.g_scores != nullptr) {
+    // dz_L = (g w_o) * c_L, then dz_{l-1} = (dz_l W_l) * c_{l-1}
+    chain_gate_init(p.g_scores, w_o, p.saved + p.h_off[L], p.w[L], B, row0, keep_scale, g.neg_slope, p.dz[L]);
+    chain_sync();
+    for (int l = L; l >= 1; --l) {
+      if (l > 1) {
+        chain_bwd_layer<PD>(p.dz[l], p.w[l], p.weight[l - 1], p.w[l - 1], B, row0, p.saved + p.h_off[l - 1], keep_scale,
+                            keep_scale * g.neg_slope, p.dz[l - 1], lds);
+        chain_sync();
+      } else if (p.dx != nullptr) {
+        chain_bwd_layer<PD>(p.dz[l], p.w[l], p.weight[l - 1], p.w[l - 1], B, row0, nullptr, 0.0f, 0.0f, p.dx, lds);
+      }
+    }
+  }
+  if (p.g_norm2 != nullptr) {
+    // e_0 = 2 g_norm2 g_0, then e_l = (e_{l-1} W_l^T) * c_l
+    const int W0 = p.w[0];
+    const float* g0 = p.saved + p.g0_off;
+    for (int i = threadIdx.x; i < kChainRows * W0; i += kThreads) {
+      const int r = row0 + i / W0, c = i % W0;
+      if (r >= B) break;
+      p.e[0][(int64_t)r * W0 + c] = 2.0f * p.g_norm2[r] * g0[(int64_t)r * W0 + c];
+    }
+    chain_sync();
+    for (int l = 1; l <= L; ++l) {
+      chain_fwd_layer<PF>(p.e[l - 1], p.w[l - 1], p.weight[l - 1], p.w[l - 1], p.w[l], B, row0, nullptr, 1.0f, 0.0f, 0, nullptr,
+                          p.saved + p.h_off[l], keep_scale, keep_scale * g.neg_slope, p.e[l], lds);
+      chain_sync();
+    }
+  }
+}
+
+// Whether a pass can go through the chain kernel: widths and strides that allow 16-byte loads everywhere.
+bool chain_ok(const Shape& s, const float* x, int64_t x_ld, const float* const* w, const float* saved) {
+  if (s.L > kChainLayers || s.B <= 0) return false;
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!al(x) || x_ld % 4 != 0 || !al(saved)) return false;
+  for (int l = 0; l <= s.L; ++l)
+    if (s.w[l] % 4 != 0 || !al(w[l])) return false;
+  return true;
+}
+
+template <int PF, int PD>
+void launch_chain(const ChainArgs& a, int backward, hipStream_t st) {
+  hipLaunchKernelGGL((critic_chain_kernel<PF, PD>), dim3((unsigned)a.first_block[a.count]), dim3(kThreads), 0, st, a,
+                     backward);
+}
+
+void launch_chain_for_mask(const ChainArgs& a, int backward, hipStream_t st) {
+  const int mask = matmul_bf16_mask();
+  const int pf = (mask & HIVT_BF16_FWD_SPLIT) ? PREC_SPLIT : ((mask & HIVT_BF16_FWD) ? PREC_BF16 : PREC_F32);
+  const bool pd = (mask & HIVT_BF16_DGRAD) != 0;
+  if (pf == PREC_SPLIT && pd) launch_chain<PREC_SPLIT, PREC_BF16>(a, backward, st);
+  else if (pf == PREC_SPLIT) launch_chain<PREC_SPLIT, PREC_F32>(a, backward, st);
+  else if (pf == PREC_BF16 && pd) launch_chain<PREC_BF16, PREC_BF16>(a, backward, st);
+  else if (pf == PREC_BF16) launch_chain<PREC_BF16, PREC_F32>(a, backward, st);
+  else if (pd) launch_chain<PREC_F32, PREC_BF16>(a, backward, st);
+  else launch_chain<PREC_F32, PREC_F32>(a, backward, st);
+}
+
 
 }  // namespace
 }  // namespace hivt
@@ -470,6 +708,200 @@ extern "C" int hivt_weighted_mean_bwd(const float* g_out, const float* w, const 
   HIVT_REQUIRE(g_out && w && count && g_s, HIVT_ERR_ARG, "%s: null pointer", what);
   hipLaunchKernelGGL(weighted_mean_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      g_out, w, count, B, scale, g_s);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several passes per call (all critics, real and generated trajectories): one chain launch for up to six passes.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct FwdPass {
+  const float* x; int64_t x_ld; int64_t B; int32_t layers; const int32_t* widths; const float* const* w;
+  const float* const* bias; uint64_t seed; int32_t with_input_grad; float* saved; float* scores; float* grad_norm2;
+};
+
+struct BwdPass {
+  const float* g_scores; const float* g_norm2; const float* x; int64_t x_ld; int64_t B; int32_t layers;
+  const int32_t* widths; const float* const* w; const float* saved; float* const* dw; float* const* dbias; float* dx;
+};
+
+template <class T> T* as_ptr(int64_t v) { return reinterpret_cast<T*>((uintptr_t)v); }
+
+size_t chain_act_bytes(const Shape& s) {
+  size_t total = 0;
+  for (int l = 1; l <= s.L; ++l) total += act_bytes(s, l);
+  for (int l = 0; l <= s.L; ++l) total += act_bytes(s, l);
+  return total;
+}
+
+void fill_common(ChainPass& c, const Shape& s, const float* x, int64_t x_ld, const float* const* w, float* saved) {
+  c.x = x; c.x_ld = x_ld; c.B = (int32_t)s.B; c.L = s.L;
+  for (int l = 0; l <= s.L; ++l) {
+    c.w[l] = s.w[l];
+    c.weight[l] = w[l];
+  }
+  c.saved = saved;
+  for (int l = 1; l <= s.L; ++l) {
+    c.h_off[l] = s.h_off[l];
+    c.g_off[l] = s.g_off[l];
+  }
+  c.g0_off = s.g0_off;
+}
+
+}  // namespace
+
+extern "C" int hivt_critics_fwd(const int64_t* passes, int32_t count, float neg_slope, float dropout_p,
+                                const uint64_t* seed_ptr, hivt_stream_t stream) {
+  const char* what = "hivt_critics_fwd";
+  HIVT_REQUIRE(count >= 0 && (count == 0 || passes != nullptr), HIVT_ERR_ARG, "%s: bad pass table", what);
+  HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
+  hipStream_t st = (hipStream_t)stream;
+  ChainArgs a{};
+  a.neg_slope = neg_slope; a.dropout_p = dropout_p; a.seed_ptr = seed_ptr;
+  auto flush = [&]() {
+    if (a.count > 0) launch_chain_for_mask(a, 0, st);
+    a.count = 0;
+    a.first_block[0] = 0;
+  };
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t* t = passes + (size_t)i * 12;
+    FwdPass f{as_ptr<const float>(t[0]), t[1], t[2], (int32_t)t[3], as_ptr<const int32_t>(t[4]),
+              as_ptr<const float* const>(t[5]), as_ptr<const float* const>(t[6]), (uint64_t)t[7], (int32_t)t[8],
+              as_ptr<float>(t[9]), as_ptr<float>(t[10]), as_ptr<float>(t[11])};
+    Shape s;
+    HIVT_TRY(make_shape(what, f.B, f.layers, f.widths, s));
+    if (f.B == 0) continue;
+    HIVT_REQUIRE(f.x && f.w && f.bias && f.saved && f.scores, HIVT_ERR_ARG, "%s: pass %d: null pointer", what, (int)i);
+    HIVT_REQUIRE(!f.with_input_grad || f.grad_norm2, HIVT_ERR_ARG, "%s: pass %d: grad_norm2 is null", what, (int)i);
+    HIVT_REQUIRE(f.x_ld >= s.w[0], HIVT_ERR_ARG, "%s: pass %d: x_ld smaller than the input width", what, (int)i);
+    for (int l = 0; l <= f.layers; ++l)
+      HIVT_REQUIRE(f.w[l] && f.bias[l], HIVT_ERR_ARG, "%s: pass %d: null parameter (layer %d)", what, (int)i, l);
+    if (!chain_ok(s, f.x, f.x_ld, f.w, f.saved)) {  // the layer-by-layer route
+      HIVT_TRY(hivt_critic_fwd(f.x, f.x_ld, f.B, f.layers, f.widths, f.w, f.bias, neg_slope, dropout_p, f.seed, seed_ptr,
+                               f.with_input_grad, f.saved, f.scores, f.grad_norm2, stream));
+      continue;
+    }
+    ChainPass& c = a.pass[a.count];
+    c = ChainPass{};
+    fill_common(c, s, f.x, f.x_ld, f.w, f.saved);
+    for (int l = 0; l <= s.L; ++l) c.bias[l] = f.bias[l];
+    c.seed = f.seed;
+    c.scores = f.scores;
+    c.grad_norm2 = f.with_input_grad ? f.grad_norm2 : nullptr;
+    a.first_block[a.count + 1] = a.first_block[a.count] + (int32_t)((s.B + kChainRows - 1) / kChainRows);
+    if (++a.count == kChainPasses) flush();
+  }
+  flush();
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" size_t hivt_critics_bwd_workspace_bytes(const int64_t* passes, int32_t count) {
+  if (count < 0 || (count > 0 && passes == nullptr)) return 0;
+  size_t total = 256;
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t* t = passes + (size_t)i * 12;
+    Shape s;
+    if (make_shape("hivt_critics_bwd_workspace_bytes", t[4], (int32_t)t[5], as_ptr<const int32_t>(t[6]), s) != HIVT_OK)
+      return 0;
+    total += scratch_bytes(s) + group_bytes(s);  // the pass's own region + its share of the grouped call's workspace
+  }
+  return total;
+}
+
+extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_slope, float dropout_p, void* workspace,
+                                size_t workspace_bytes, hivt_stream_t stream) {
+  const char* what = "hivt_critics_bwd";
+  HIVT_REQUIRE(count >= 0 && (count == 0 || passes != nullptr), HIVT_ERR_ARG, "%s: bad pass table", what);
+  HIVT_REQUIRE(workspace_bytes >= hivt_critics_bwd_workspace_bytes(passes, count) && (count == 0 || workspace),
+               HIVT_ERR_WORKSPACE, "%s: workspace too small", what);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = reinterpret_cast<char*>(workspace);
+  struct Done { Shape s; BwdPass b; Scratch k; bool chained, scores_chain, penalty_chain, params; };
+  std::vector<Done> done;
+  ChainArgs a{};
+  a.neg_slope = neg_slope; a.dropout_p = dropout_p;
+  auto flush = [&]() {
+    if (a.count > 0) launch_chain_for_mask(a, 1, st);
+    a.count = 0;
+    a.first_block[0] = 0;
+  };
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t* t = passes + (size_t)i * 12;
+    BwdPass b{as_ptr<const float>(t[0]), as_ptr<const float>(t[1]), as_ptr<const float>(t[2]), t[3], t[4], (int32_t)t[5],
+              as_ptr<const int32_t>(t[6]), as_ptr<const float* const>(t[7]), as_ptr<const float>(t[8]),
+              as_ptr<float* const>(t[9]), as_ptr<float* const>(t[10]), as_ptr<float>(t[11])};
+    Shape s;
+    HIVT_TRY(make_shape(what, b.B, b.layers, b.widths, s));
+    char* region = ws;
+    ws += scratch_bytes(s);
+    const bool params = b.dw != nullptr || b.dbias != nullptr;
+    const bool trivial = b.B == 0 || (b.g_scores == nullptr && b.g_norm2 == nullptr) || (!params && b.g_scores == nullptr);
+    if (trivial || !(b.x && b.w && b.saved) || !chain_ok(s, b.x, b.x_ld, b.w, b.saved)) {
+      // nothing to chain (or not chainable): the single-pass entry point covers every corner
+      HIVT_TRY(hivt_critic_bwd(b.g_scores, b.g_norm2, b.x, b.x_ld, b.B, b.layers, b.widths, b.w, neg_slope, dropout_p,
+                               b.saved, b.dw, b.dbias, b.dx, region, scratch_bytes(s), stream));
+      continue;
+    }
+    HIVT_REQUIRE(!params || (b.dw && b.dbias), HIVT_ERR_ARG, "%s: pass %d: dw and dbias go together", what, (int)i);
+    HIVT_REQUIRE(params || (b.g_norm2 == nullptr && b.dx != nullptr), HIVT_ERR_ARG,
+                 "%s: pass %d: without parameter gradients the call computes dx from g_scores only", what, (int)i);
+    if (params)
+      for (int l = 0; l <= s.L; ++l)
+        HIVT_REQUIRE(b.dw[l] && b.dbias[l], HIVT_ERR_ARG, "%s: pass %d: null gradient (layer %d)", what, (int)i, l);
+    Done d;
+    d.s = s; d.b = b; d.k = carve(s, region); d.chained = true; d.params = params;
+    d.scores_chain = b.g_scores != nullptr; d.penalty_chain = b.g_norm2 != nullptr;
+    if (!d.scores_chain) {  // penalty gradients only: the bias gradients (and dx) of the score chain are zero
+      for (int l = 1; l <= s.L; ++l) zero_words(b.dbias[l - 1], s.w[l], st);
+      zero_words(b.dbias[s.L], 1, st);
+      if (b.dx != nullptr) zero_words(b.dx, b.B * s.w[0], st);
+    }
+    ChainPass& c = a.pass[a.count];
+    c = ChainPass{};
+    fill_common(c, s, b.x, b.x_ld, b.w, const_cast<float*>(b.saved));
+    c.g_scores = b.g_scores; c.g_norm2 = b.g_norm2; c.dx = b.dx;
+    for (int l = 1; l <= s.L; ++l) c.dz[l] = d.k.dz[l];
+    for (int l = 0; l <= s.L; ++l) c.e[l] = d.k.e[l];
+    a.first_block[a.count + 1] = a.first_block[a.count] + (int32_t)((s.B + kChainRows - 1) / kChainRows);
+    done.push_back(d);
+    if (++a.count == kChainPasses) flush();
+  }
+  flush();
+  HIVT_CHECK_LAUNCH(what);
+  // the weight gradients of every chained pass in ONE grouped call; its workspace is what lies behind the passes'
+  // own regions (hivt_critics_bwd_workspace_bytes reserves every pass's share there)
+  std::vector<int64_t> table;
+  int32_t terms = 0;
+  for (const Done& d : done) {
+    if (!d.params) continue;
+    const Shape& s = d.s;
+    const BwdPass& b = d.b;
+    Terms t;
+    if (d.scores_chain)
+      t.add(b.g_scores, 1, b.saved + s.h_off[s.L], s.w[s.L], b.B, 1, s.w[s.L], b.dw[s.L], b.dbias[s.L], false, false);
+    for (int l = s.L; l >= 1; --l) {
+      const float* h_prev = l > 1 ? b.saved + s.h_off[l - 1] : b.x;
+      const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : b.x_ld;
+      if (d.scores_chain)
+        t.add(d.k.dz[l], s.w[l], h_prev, h_prev_ld, b.B, s.w[l], s.w[l - 1], b.dw[l - 1], b.dbias[l - 1], false, false);
+      if (d.penalty_chain)
+        t.add(b.saved + s.g_off[l], s.w[l], d.k.e[l - 1], s.w[l - 1], b.B, s.w[l], s.w[l - 1], b.dw[l - 1], nullptr, false,
+              d.scores_chain);
+    }
+    table.insert(table.end(), &t.row[0][0], &t.row[0][0] + (size_t)t.count * 10);
+    terms += t.count;
+  }
+  if (terms > 0) {
+    const size_t left = workspace_bytes - (size_t)(ws - reinterpret_cast<char*>(workspace));
+    HIVT_TRY(hivt_linear_wgrad_group(table.data(), terms, ws, left, stream));
+  }
+  for (const Done& d : done) {
+    if (!d.params || !d.penalty_chain) continue;
+    reduce_partials(d.k.e[d.s.L], (int)d.b.B, d.s.w[d.s.L], d.b.dw[d.s.L], st, d.scores_chain);
+  }
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .critics import multi_supported, scores_multi
 
 
 # The critics are independent small networks (a few thousand rows each), so one of them fills a fraction
@@ -144,7 +145,15 @@ class AdversarialDiscriminatorLoss(nn.Module):
             return loss, r1.detach()
 
         total, logs = 0.0, {}
-        for name, (loss, r1) in zip(critics, per_critic(critics, (real, fake, w, cnt), one)):
+        if multi_supported(critics.values(), real, fake):
+            # every critic on the real and on the generated rows in one library call (their launches are shared)
+            members = list(critics.values())
+            outs = scores_multi([(c, real, True) for c in members] + [(c, fake, False) for c in members])
+            terms = [ops.hinge_r1_loss(outs[i][0], outs[i][1], outs[len(members) + i], w, cnt, self.lambda_r1)
+                     for i in range(len(members))]
+        else:
+            terms = per_critic(critics, (real, fake, w, cnt), one)
+        for name, (loss, r1) in zip(critics, terms):
             total = total + loss
             logs[f"d_loss_{name}"] = loss.detach()
             logs[f"r1_{name}"] = r1
@@ -176,7 +185,12 @@ class AdversarialGeneratorLoss(nn.Module):
                 return (ops.weighted_mean(scores, w, cnt, -1.0),)
             return (-(scores * w).sum() / cnt,)
 
-        for name, (g,) in zip(critics, per_critic(critics, (fake, w, cnt), one)):
+        if multi_supported(critics.values(), fake):
+            outs = scores_multi([(c, fake, False) for c in critics.values()])
+            terms = [(ops.weighted_mean(s, w, cnt, -1.0),) for s in outs]
+        else:
+            terms = per_critic(critics, (fake, w, cnt), one)
+        for name, (g,) in zip(critics, terms):
             total = total + g
             logs[f"g_loss_{name}"] = g.detach()
         return self.lambda_adv * total, logs

@@ -1059,11 +1059,11 @@ class _SpectralNormalize(torch.autograd.Function):
 
 
 def spectral_normalize(weights, us, vs, training: bool, eps: float = 1e-12):
-    """Spectrally normalised copies of ``weights`` (a list of [out, in] matrices, at most 8).  ``us`` /
+    """Spectrally normalised copies of ``weights`` (a list of [out, in] matrices, at most 16).  ``us`` /
     ``vs`` are the persistent power-iteration vectors; in training mode they advance by one iteration
     (in place), exactly as the hook of ``torch.nn.utils.spectral_norm`` does per forward call."""
-    if len(weights) > 8:
-        raise ValueError("at most 8 layers per call")
+    if len(weights) > 16:
+        raise ValueError("at most 16 layers per call")
     for w, u, v in zip(weights, us, vs):
         if w.dim() != 2 or u.shape != (w.shape[0],) or v.shape != (w.shape[1],):
             raise ValueError("weights must be [out, in] with u [out] and v [in]")
@@ -1223,6 +1223,148 @@ def critic_scores(x: torch.Tensor, weights, biases, neg_slope: float, dropout_p:
     params = [t for pair in zip(weights, biases) for t in pair]
     cfg = (float(neg_slope), p, _fresh_seed() if p > 0.0 else 0, bool(with_input_grad_norm))
     return _Critic.apply(x, cfg, *params)
+
+
+class _CriticsMulti(torch.autograd.Function):
+    """Several critic passes (all critics, real and generated trajectories) per library call: forward and
+    backward are one call each, and the passes share their launches.  ``plan`` lists per pass ``(layers + 1,
+    with_r1, seed)``; the tensors follow as ``x, w_1, b_1, .., w_o, b_o`` per pass.  Outputs per pass: scores
+    [B] and, with ``with_r1``, ``||d score / d x||^2`` [B]."""
+
+    @staticmethod
+    def forward(ctx, cfg, plan, *tensors):
+        neg_slope, dropout_p = cfg
+        passes, table, keep, outs = [], [], [], []
+        at = 0
+        for n_lin, with_r1, seed in plan:
+            x = tensors[at]
+            params = tensors[at + 1:at + 1 + 2 * n_lin]
+            at += 1 + 2 * n_lin
+            weights = [p.contiguous() for p in params[0::2]]
+            biases = [p.contiguous() for p in params[1::2]]
+            _need_gpu(x, *weights)
+            layers = n_lin - 1
+            x2 = x.reshape(x.shape[0], -1)
+            if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]) or x2.dtype != torch.float32:
+                x2 = x2.contiguous().float()
+            b = x2.shape[0]
+            widths_list = [x2.shape[1]] + [w.shape[0] for w in weights[:-1]]
+            for l, w in enumerate(weights[:-1]):
+                if w.shape[1] != widths_list[l]:
+                    raise ValueError("critic layer widths do not chain")
+            if weights[-1].shape != (1, widths_list[-1]):
+                raise ValueError("the output layer must be [1, hidden]")
+            dev = x2.device
+            widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
+            w_ptrs, b_ptrs = _ptr_array(weights), _ptr_array(biases)
+            saved = torch.empty(_lib.query("hivt_critic_saved_floats", b, layers, tuple(widths_list), int(with_r1)),
+                                dtype=torch.float32, device=dev)
+            scores = torch.empty(b, dtype=torch.float32, device=dev)
+            gn2 = torch.empty(b, dtype=torch.float32, device=dev) if with_r1 else None
+            table += [x2.data_ptr(), x2.stride(0) if b > 0 else widths_list[0], b, layers, ctypes.addressof(widths),
+                      ctypes.addressof(w_ptrs), ctypes.addressof(b_ptrs), int(seed), int(with_r1), saved.data_ptr(),
+                      scores.data_ptr(), gn2.data_ptr() if with_r1 else 0]
+            keep.append((widths, w_ptrs, b_ptrs))
+            passes.append((x2, saved, weights, widths_list, tuple(x.shape), [tuple(t.shape) for t in biases], bool(with_r1)))
+            outs.append(scores)
+            if with_r1:
+                outs.append(gn2)
+        dev = passes[0][0].device
+        arr = (ctypes.c_int64 * len(table))(*table)
+        _lib.call("hivt_critics_fwd", arr, len(passes), float(neg_slope), float(dropout_p), _seed_ptr(dropout_p),
+                  torch._C._cuda_getCurrentRawStream(dev.index))
+        del keep
+        flat = []
+        for x2, saved, weights, *_ in passes:
+            flat += [x2, saved, *weights]
+        ctx.save_for_backward(*flat)
+        ctx.meta = [(len(weights), widths_list, x_shape, bias_shapes, with_r1)
+                    for _, _, weights, widths_list, x_shape, bias_shapes, with_r1 in passes]
+        ctx.cfg = (float(neg_slope), float(dropout_p))
+        ctx.plan = plan
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        neg_slope, dropout_p = ctx.cfg
+        saved_tensors = ctx.saved_tensors
+        table, keep, results = [], [], []
+        at, out_at, in_at = 0, 0, 2  # positions in saved tensors, grad outputs, forward inputs (after cfg, plan)
+        dev = saved_tensors[0].device
+        for n_lin, widths_list, x_shape, bias_shapes, with_r1 in ctx.meta:
+            x2, saved = saved_tensors[at], saved_tensors[at + 1]
+            weights = list(saved_tensors[at + 2:at + 2 + n_lin])
+            at += 2 + n_lin
+            g_scores = gouts[out_at]
+            g_norm2 = gouts[out_at + 1] if with_r1 else None
+            out_at += 2 if with_r1 else 1
+            need_x = ctx.needs_input_grad[in_at]
+            need_params = any(ctx.needs_input_grad[in_at + 1:in_at + 1 + 2 * n_lin])
+            in_at += 1 + 2 * n_lin
+            layers = n_lin - 1
+            b = x2.shape[0]
+            gs = g_scores.contiguous() if g_scores is not None else None
+            gn = g_norm2.contiguous() if g_norm2 is not None else None
+            dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if need_x else None
+            dws = dbs = None
+            if need_params:
+                dws = [torch.empty_like(w) for w in weights]
+                dbs = [torch.empty(s, dtype=torch.float32, device=dev) for s in bias_shapes]
+            elif not need_x:
+                results.append((None, None, None, n_lin, x_shape))
+                continue
+            widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
+            w_ptrs = _ptr_array(weights)
+            dw_ptrs = _ptr_array(dws) if dws is not None else None
+            db_ptrs = _ptr_array(dbs) if dbs is not None else None
+            table += [gs.data_ptr() if gs is not None else 0, gn.data_ptr() if (gn is not None and need_params) else 0,
+                      x2.data_ptr(), x2.stride(0) if b > 0 else widths_list[0], b, layers, ctypes.addressof(widths),
+                      ctypes.addressof(w_ptrs), saved.data_ptr(), ctypes.addressof(dw_ptrs) if dw_ptrs is not None else 0,
+                      ctypes.addressof(db_ptrs) if db_ptrs is not None else 0, dx.data_ptr() if dx is not None else 0]
+            keep.append((widths, w_ptrs, dw_ptrs, db_ptrs, gs, gn))
+            results.append((dx, dws, dbs, n_lin, x_shape))
+        if table:
+            count = len(table) // 12
+            arr = (ctypes.c_int64 * len(table))(*table)
+            ws = _workspace(_lib.value("hivt_critics_bwd_workspace_bytes", arr, count), dev)
+            _lib.call("hivt_critics_bwd", arr, count, neg_slope, dropout_p, _p(ws), ws.numel(),
+                      torch._C._cuda_getCurrentRawStream(dev.index))
+        del keep
+        grads = [None, None]
+        for dx, dws, dbs, n_lin, x_shape in results:
+            grads.append(dx.view(x_shape) if dx is not None else None)
+            if dws is None:
+                grads += [None] * (2 * n_lin)
+            else:
+                for dw, db in zip(dws, dbs):
+                    grads += [dw, db]
+        return tuple(grads)
+
+
+def critic_scores_multi(passes, neg_slope: float, dropout_p: float, training: bool):
+    """``passes``: tuples ``(x, weights, biases, with_input_grad_norm)``, one per critic pass (the layout of
+    ``critic_scores``; all passes share the LeakyReLU slope and the dropout rate).  Returns per pass ``scores`` or
+    ``(scores, grad_norm2)``; all passes run in one library call forward and one backward."""
+    p = float(dropout_p) if training else 0.0
+    plan, tensors = [], []
+    for x, weights, biases, with_r1 in passes:
+        if len(weights) != len(biases) or not 2 <= len(weights) <= 9:
+            raise ValueError("a critic has 1..8 hidden layers and an output layer")
+        plan.append((len(weights), bool(with_r1), _fresh_seed() if p > 0.0 else 0))
+        tensors.append(x)
+        tensors += [t for pair in zip(weights, biases) for t in pair]
+    outs = _CriticsMulti.apply((float(neg_slope), p), tuple(plan), *tensors)
+    result, at = [], 0
+    for _, _, _, with_r1 in passes:
+        if with_r1:
+            result.append((outs[at], outs[at + 1]))
+            at += 2
+        else:
+            result.append(outs[at])
+            at += 1
+    return result
 
 
 # --------------------------------------------------------------------------------------------

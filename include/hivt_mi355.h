@@ -417,7 +417,7 @@ int hivt_embed2_bwd(const float* dh, const float* f, int64_t f_ld, int32_t branc
  * Spectral normalisation of the critics' linear layers
  * ------------------------------------------------------------------------------------------ */
 
-#define HIVT_SPECTRAL_MAX_LAYERS 8 /* layers per call */
+#define HIVT_SPECTRAL_MAX_LAYERS 16 /* layers per call (all layers of the three critics fit one) */
 
 /* One power iteration and the division by the singular-value estimate for `layers` weight matrices
  * in ONE launch (one workgroup per layer).  Replaces, per layer and per forward call, the hook that
@@ -475,6 +475,23 @@ int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x,
                     int32_t layers, const int32_t* widths, const float* const* w, float neg_slope, float dropout_p,
                     const float* saved, float* const* dw, float* const* dbias, float* dx, void* workspace,
                     size_t workspace_bytes, hivt_stream_t stream);
+
+/* The same passes, several per call: models/hivt.py:244-252 and :317-323 evaluate the three critics on the real
+ * and on the generated trajectories one after the other; here up to six such passes share every launch (a
+ * workgroup carries 64 rows of one pass through all of its layers).
+ *   hivt_critics_fwd   passes: count rows of 12 int64 -- x, x_ld, B, layers, widths (host int32*), w (host
+ *                      float**), bias (host float**), seed, with_input_grad, saved, scores, grad_norm2; the
+ *                      meaning of every field is that of the hivt_critic_fwd argument of the same name.
+ *   hivt_critics_bwd   rows of 12 int64 -- g_scores, g_norm2, x, x_ld, B, layers, widths, w, saved, dw (host
+ *                      float** or 0), dbias (host float** or 0), dx; as hivt_critic_bwd.
+ * Results are those of one hivt_critic_fwd / hivt_critic_bwd call per pass (scores: an fp32 dot product in
+ * place of the matrix-core product, so equal to rounding).  Passes with more than four hidden layers, widths
+ * that are not multiples of 4 or operands that are not 16-byte aligned take that single-pass route. */
+int hivt_critics_fwd(const int64_t* passes, int32_t count, float neg_slope, float dropout_p, const uint64_t* seed_ptr,
+                     hivt_stream_t stream);
+size_t hivt_critics_bwd_workspace_bytes(const int64_t* passes, int32_t count);
+int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_slope, float dropout_p, void* workspace,
+                     size_t workspace_bytes, hivt_stream_t stream);
 
 /* Critic loss of one scale (losses/adv_losses.py:36-58 with losses/r1_regularization.py:27-36), over all
  * B rows with per-row weights w (0/1 keep mask) instead of boolean-indexed subsets:
