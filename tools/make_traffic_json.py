@@ -10,18 +10,24 @@ import re
 import sys
 
 src, tag, embed_dim, scenes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-def caller(glob, split):
-    """Which module launches a kernel instance: node terms -> interaction module, one row per lane slot ->
-    agent-agent stage (1.3 edges per row), otherwise the lane-actor stage."""
-    return "GlobalInteractorLayer" if glob == "true" else ("AAEncoder" if split == "true" else "ALEncoder")
+def caller(glob, split, wpn, unroll):
+    """Which module launches a kernel instance on the benchmark's workload: node terms -> interaction module, one
+    row per lane slot -> agent-agent stage (1.3 edges per row), four waves per row with eight edges in flight
+    -> lane-actor stage (52 edges per row), the remaining shapes -> the temporal encoder's last layer (21 steps
+    per agent)."""
+    if glob == "true":
+        return "GlobalInteractorLayer"
+    if split == "true":
+        return "AAEncoder"
+    return "ALEncoder" if (wpn == "4" and unroll == "8") else "TemporalEncoderLayer"
 out = {}
 for name, scale in (("pmc_fetch_size.csv", 2 * 1024.0), ("pmc_write_size.csv", 1024.0)):
     for r in csv.DictReader(open(f"{src}/{name}")):
         m = re.search(r"seg_attn_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?>", r["kernel"])
         if not m:
             continue
-        kind, _d, _lph, _wpn, glob, split, _unroll = m.groups()
-        key = f"{kind}/{caller(glob, split)}"
+        kind, _d, _lph, wpn, glob, split, unroll = m.groups()
+        key = f"{kind}/{caller(glob, split, wpn, unroll)}"
         e = out.setdefault(key, {"read_bytes": 0.0, "write_bytes": 0.0})
         e["read_bytes" if "fetch" in name else "write_bytes"] += float(r["mean_per_dispatch"]) * scale
 for e in out.values():
