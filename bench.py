@@ -14,10 +14,12 @@ with fp32 accumulation (everything else, and all tensors in memory, fp32); ``--m
 step in fp32 throughout.  The other setting is timed after the headline measurement and reported as
 ``matmul_variant``.
 
-The ``roofline`` object describes the dominant edge-attention kernel (segment-softmax attention
-forward over all 20 timesteps' agent-agent edges): algorithmic bytes of one launch divided by its
-average duration, measured with device events around each of its launches inside the timed
-region.  ``cpu_baseline`` times the CPU oracle's restatement of the same step on a bounded sample
+The ``roofline`` object describes the edge-attention launch kind that takes the most time per step:
+algorithmic bytes of one launch divided by its average duration (the kernel's own start / stop time
+stamps).  Every launch kind is listed under ``edge_attention_kernels`` with, beside its fraction of
+8 TB/s, the time a plain device copy of the same byte count takes on this GPU in this run
+(``copy_same_bytes_us``; ``rate_vs_copy`` > 1 means the attention launch moves its bytes faster than
+that copy).  ``cpu_baseline`` times the CPU oracle's restatement of the same step on a bounded sample
 of the same workload (rank 0, single-GPU runs only).
 """
 import argparse
@@ -63,6 +65,25 @@ def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool, 
         if node_terms:
             b += n * 2 * d * s + e * 4
     return float(b)
+
+
+def copy_same_bytes_us(nbytes: float, device, repeats: int = 15) -> float:
+    """Median microseconds of a plain device copy that moves ``nbytes`` in total (half read, half written):
+    the rate this device delivers to the simplest streaming kernel at the byte count of one launch, which
+    for launches of 50-300 MB is well under the 8 TB/s the roofline is quoted against."""
+    n = max(int(nbytes) // 8, 1)
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    times = []
+    for i in range(repeats + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        if i >= 3:
+            times.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(times)[len(times) // 2]
 
 
 def measured_traffic(embed_dim: int, scenes: int):
@@ -343,6 +364,8 @@ def main():
                      "rows_per_launch": sum(r[0] for r in rows) / len(rows),
                      "rows_with_edges_per_launch": sum(r[3] for r in rows) / len(rows)}
             entry["us_per_step"] = tm * 1e6 * len(rows) / args.steps
+            entry["copy_same_bytes_us"] = copy_same_bytes_us(by, dev)
+            entry["rate_vs_copy"] = entry["copy_same_bytes_us"] / entry["avg_launch_us"]
             extra.append(entry)
         # dominant kernel = the edge-attention launch kind that takes the most time per step
         if extra:
