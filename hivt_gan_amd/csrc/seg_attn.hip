@@ -97,11 +97,19 @@ __device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, flo
   m = mn;
 }
 
+// KIND = where the K / V rows of a target come from (a compile-time choice: the three kinds are distinct kernels,
+//        so a profile tells them apart by name)
+constexpr int kRowsPlain = 0;        // edge e of the CSR order is row e
+constexpr int kRowsNodeTerms = 1;    // row e plus the row of the edge's source node (gathered through src)
+constexpr int kRowsInterleaved = 2;  // step-major rows: the j-th edge of target n is row j * N + n
+
 // WPN  = waves that share one target row (1, or 4 for long rows, merged through LDS)
 // SPLIT = short-row mode: every lane slot (LPR lanes) of a wave owns its OWN target row, so a wave
 //         serves 64/LPR rows at once and no slot merge is needed (requires WPN == 1)
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL>
 __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) {
+  constexpr bool GLOBAL = KIND == kRowsNodeTerms;
+  constexpr bool INTERLEAVED = KIND == kRowsInterleaved;
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
 
   const int beg = a.rowptr[nc];
   int end = row_ok ? a.rowptr[nc + 1] : beg;
-  if (a.row_interleave) end = min(end, beg + a.seg_len);
+  if (INTERLEAVED) end = min(end, beg + a.seg_len);
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (end > beg) {  // rows without edges never need their query
     qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
       const int e = e0 + u * STRIDE;
       ok[u] = e < end;
       const int64_t ee = ok[u] ? e : e0;
-      const int64_t er = a.row_interleave ? (ee - beg) * a.row_interleave + nc : ee;
+      const int64_t er = INTERLEAVED ? (ee - beg) * a.row_interleave + nc : ee;
       kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
       vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
       if (GLOBAL) {
@@ -220,8 +228,10 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL>
 __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
+  constexpr bool GLOBAL = KIND == kRowsNodeTerms;
+  constexpr bool INTERLEAVED = KIND == kRowsInterleaved;
   constexpr int LPR = D / 4;
   constexpr int EPI = kWave / LPR;
   constexpr int NPB = 4 / WPN;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
 
   const int beg = a.rowptr[nc];
   int end = row_ok ? a.rowptr[nc + 1] : beg;
-  if (a.row_interleave) end = min(end, beg + a.seg_len);
+  if (INTERLEAVED) end = min(end, beg + a.seg_len);
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs;
   float delta = 0.0f, mh = 0.0f, inv_den = 0.0f;
   if (end > beg) {
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
       const int e = e0 + u * STRIDE;
       ok[u] = e < end;
       const int64_t ee = ok[u] ? e : e0;
-      const int64_t er = a.row_interleave ? (ee - beg) * a.row_interleave + nc : ee;
+      const int64_t er = INTERLEAVED ? (ee - beg) * a.row_interleave + nc : ee;
       kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
       vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
       if (GLOBAL) {
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
         }
         const float am = alpha * ms;
         const float ds = alpha * (dav * ms - delta);
-        const int64_t er = a.row_interleave ? (e - beg) * a.row_interleave + nc : e;
+        const int64_t er = INTERLEAVED ? (e - beg) * a.row_interleave + nc : e;
         *reinterpret_cast<float4*>(a.dv + er * a.dkv_stride + 4 * c) =
             make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
         *reinterpret_cast<float4*>(a.dk + er * a.dkv_stride + 4 * c) =
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(256) void zero_tail_kernel(const int32_t* __restric
   }
 }
 
-template <int D, int LPH, int WPN, bool GLOBAL, bool SPLIT, int UNROLL>
+template <int D, int LPH, int WPN, int GLOBAL, bool SPLIT, int UNROLL>
 int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? kWave / (D / 4) : 1;
@@ -365,8 +375,9 @@ int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
 
 template <int D, int LPH, int WPN, bool SPLIT, int UNROLL>
 int launch_g(bool backward, bool global, const SegAttnArgs& a, hipStream_t stream) {
-  return global ? launch_one<D, LPH, WPN, true, SPLIT, UNROLL>(backward, a, stream)
-                : launch_one<D, LPH, WPN, false, SPLIT, UNROLL>(backward, a, stream);
+  if (global) return launch_one<D, LPH, WPN, kRowsNodeTerms, SPLIT, UNROLL>(backward, a, stream);
+  if (a.row_interleave) return launch_one<D, LPH, WPN, kRowsInterleaved, SPLIT, UNROLL>(backward, a, stream);
+  return launch_one<D, LPH, WPN, kRowsPlain, SPLIT, UNROLL>(backward, a, stream);
 }
 
 // Launch shapes.  `waves`: 0 = one target row per lane slot (short rows), 1 / 2 / 4 = waves of a block that

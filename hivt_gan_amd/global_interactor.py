@@ -2,9 +2,9 @@
 (``models/global_interactor.py``), on the same kernels as the local encoder.
 
 Per layer the key / value of an edge is ``lin_*_node(x[src]) + lin_*_edge(rel_embed[e])``.  The node
-terms are projected once per NODE ([N, 2D], gathered by source id inside the attention kernel) and
-only the edge terms are projected per edge (one fused [E, D] x [D, 2D] GEMM), which is exactly
-equal to projecting the lifted rows (``global_interactor.py:115-119``).
+terms are projected once per NODE ([N, 2D]) and only the edge terms are projected per edge (one fused
+[E, D] x [D, 2D] product whose store epilogue adds the source node's row), which is exactly equal to
+projecting the lifted rows (``global_interactor.py:115-119``).
 """
 from __future__ import annotations
 
@@ -64,11 +64,19 @@ class GlobalInteractorLayer(nn.Module):
         edges.group_by_source()
         q = _linear(x, self.lin_q_node)
         kv_node = _fused_linear(x, self.lin_k_node, self.lin_v_node)
-        kv_edge = _fused_linear(edge_attr, self.lin_k_edge, self.lin_v_edge)
-        agg = ops.seg_attn(q, kv_edge, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
-                           kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
-                           perm_by_src=edges.perm_by_src, tag=type(self).__name__,
-                           padded=edges.count is not None)
+        if edge_attr.is_cuda and edge_attr.dtype == torch.float32 and edges.src.dtype == torch.int32:
+            # key | value of an edge = edge terms + its source node's terms: the node rows are added where the edge
+            # projection stores its tiles, and the attention kernels stream finished rows (no gathers in them)
+            kv = ops.pair_linear(edge_attr, self.lin_k_edge, self.lin_v_edge, table=kv_node, index=edges.src,
+                                 rowptr_by_index=edges.rowptr_by_src, perm_by_index=edges.perm_by_src)
+            agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
+                               tag=type(self).__name__, padded=edges.count is not None)
+        else:
+            kv_edge = _fused_linear(edge_attr, self.lin_k_edge, self.lin_v_edge)
+            agg = ops.seg_attn(q, kv_edge, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
+                               kv_node=kv_node, src=edges.src, rowptr_by_src=edges.rowptr_by_src,
+                               perm_by_src=edges.perm_by_src, tag=type(self).__name__,
+                               padded=edges.count is not None)
         if residual is not None:
             return ops.gated_update_tail(agg, x, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
                                          self.proj_drop.p, self.proj_drop.training)

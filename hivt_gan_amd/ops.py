@@ -816,7 +816,7 @@ class _PairLinear(torch.autograd.Function):
     weight-gradient product for two layers that read the same rows."""
 
     @staticmethod
-    def forward(ctx, x, w_a, b_a, w_b, b_b):
+    def forward(ctx, x, w_a, b_a, w_b, b_b, table=None, index=None, rowptr_by_index=None, perm_by_index=None):
         _need_gpu(x, w_a, w_b)
         lead = x.shape[:-1]
         x2 = _rows2(x)
@@ -827,18 +827,28 @@ class _PairLinear(torch.autograd.Function):
         b = _stacked(b_a, b_b)
         n = w.shape[0]
         y = torch.empty(m, n, dtype=torch.float32, device=x.device)
-        _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w), w.stride(0), _p(b), None, 0, None, 0, None, None, 0.0,
+        if table is not None:
+            # row i of the result also receives row index[i] of `table` (the per-source-node terms of an edge's
+            # key | value): added where the product's tile is stored, so that no later kernel gathers them
+            table = _rows2(table)
+            if table.shape[1] != n or index is None or index.shape[0] != m or index.dtype != torch.int32:
+                raise ValueError("table rows: need table [R, n_a + n_b] and one int32 row index per input row")
+            if table.shape[0] == 0 and m > 0:
+                raise ValueError("table rows: empty table")
+        _lib.call("hivt_linear_fwd", _p(x2), x2.stride(0), _p(w), w.stride(0), _p(b), _p(table),
+                  table.stride(0) if table is not None else 0, _p(index) if table is not None else None,
+                  table.shape[0] if table is not None else 0, None, None, 0.0,
                   EPI_NONE, 1.0, 0.0, 0, None, None, 0, m, n, k, _p(y), n, None, 0, None, _stream(x))
-        ctx.save_for_backward(x2, w)
-        ctx.cfg = (tuple(lead), int(w_a.shape[0]))
+        ctx.save_for_backward(x2, w, rowptr_by_index, perm_by_index)
+        ctx.cfg = (tuple(lead), int(w_a.shape[0]), table.shape[0] if table is not None else 0)
         ctx.param_leaves = _all_leaves(w_a, b_a, w_b, b_b)
         return y.view(*lead, n)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
-        lead, n_a = ctx.cfg
+        x2, w, rowptr_by_index, perm_by_index = ctx.saved_tensors
+        lead, n_a, table_rows = ctx.cfg
         m, k = x2.shape
         n = w.shape[0]
         dev = x2.device
@@ -851,12 +861,28 @@ class _PairLinear(torch.autograd.Function):
                       _p(dx), k, s)
             dx = dx.view(*lead, k)
         dw, db = _weight_grad(dy2, dy2.stride(0), x2, x2.stride(0), m, n, k, dev, leaves=ctx.param_leaves)
-        return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:]
+        d_table = None
+        if table_rows and ctx.needs_input_grad[5]:
+            # every table row receives the sum of the gradient rows that picked it, in the fixed order of the
+            # grouping by index (no atomics)
+            d_table = torch.empty(table_rows, n, dtype=torch.float32, device=dev)
+            _lib.call("hivt_segment_sum_rows", _p(dy2), dy2.stride(0), n, _p(rowptr_by_index), _p(perm_by_index),
+                      table_rows, _p(d_table), n, s)
+        return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:], d_table, None, None, None
 
 
-def pair_linear(x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear) -> torch.Tensor:
-    """``[a(x) | b(x)]`` as one product (GPU float32 tensors; both layers with a bias)."""
-    return _PairLinear.apply(x, a.weight, a.bias, b.weight, b.bias)
+def pair_linear(x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear, table: Optional[torch.Tensor] = None,
+                index: Optional[torch.Tensor] = None, rowptr_by_index: Optional[torch.Tensor] = None,
+                perm_by_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[a(x) | b(x)]`` as one product (GPU float32 tensors; both layers with a bias).  With ``table`` [R, n_a + n_b]
+    and ``index`` (int32, one entry per row of ``x``) row i of the result is ``[a(x_i) | b(x_i)] + table[index[i]]``;
+    the table's gradient needs the rows grouped by index (``rowptr_by_index`` [R + 1], ``perm_by_index``: grouped
+    position -> row)."""
+    if table is None:
+        return _PairLinear.apply(x, a.weight, a.bias, b.weight, b.bias)
+    if table.requires_grad and (rowptr_by_index is None or perm_by_index is None):
+        raise ValueError("gradient of the table rows needs the grouping of the rows by index")
+    return _PairLinear.apply(x, a.weight, a.bias, b.weight, b.bias, table, index, rowptr_by_index, perm_by_index)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -958,3 +958,49 @@ def test_seg_attn_over_interleaved_rows(steps, n, d, h):
     assert torch.equal(g_csr, got[1])
     with pytest.raises(ValueError):
         ops.seg_attn(q, kv.view(steps * n, 2 * d)[:-1], rowptr, h, interleaved=True)
+
+
+@pytest.mark.parametrize("m,rows,D", [(2500, 12, 128), (46_000, 2600, 128), (700, 30, 64), (1, 1, 128), (300, 500, 64)])
+def test_pair_linear_adds_table_rows(m, rows, D):
+    """[a(x) | b(x)] + table[index]: the per-source-node key | value rows of the interaction module enter in the
+    store epilogue of the edge projection (global_interactor.py:115-119); values and every gradient against the
+    stock ops, the table's gradient summed in a fixed order (repeatable bit for bit)."""
+    gen = torch.Generator().manual_seed(m + rows)
+    x = torch.randn(m, D, generator=gen)
+    a, b = torch.nn.Linear(D, D), torch.nn.Linear(D, D)
+    table = torch.randn(rows, 2 * D, generator=gen)
+    index = torch.randint(0, rows, (m,), generator=gen)
+    if rows > 3:
+        index[index == 1] = 0  # a table row nobody picks: its gradient is exactly zero
+    w = torch.randn(m, 2 * D, generator=gen)
+    ag, bg = torch.nn.Linear(D, D).to(DEV), torch.nn.Linear(D, D).to(DEV)
+    ag.load_state_dict(a.state_dict())
+    bg.load_state_dict(b.state_dict())
+    idx_g = index.int().to(DEV)
+    rp, pp = ops.csr_build(idx_g, rows)
+    xg, tg = x.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
+    y = ops.pair_linear(xg, ag, bg, table=tg, index=idx_g, rowptr_by_index=rp, perm_by_index=pp)
+    (y * w.to(DEV)).sum().backward()
+    xd, td = x.double().requires_grad_(True), table.double().requires_grad_(True)
+    ad, bd = torch.nn.Linear(D, D).double(), torch.nn.Linear(D, D).double()
+    ad.load_state_dict(a.state_dict())
+    bd.load_state_dict(b.state_dict())
+    ref = torch.cat([ad(xd), bd(xd)], dim=-1) + td[index]
+    (ref * w.double()).sum().backward()
+    close(y, ref, msg="y")
+    close(xg.grad, xd.grad, msg="dx")
+    close(tg.grad, td.grad, msg="dtable")
+    for name, got, want in (("dw_a", ag.weight.grad, ad.weight.grad), ("db_a", ag.bias.grad, ad.bias.grad),
+                            ("dw_b", bg.weight.grad, bd.weight.grad), ("db_b", bg.bias.grad, bd.bias.grad)):
+        close(got, want, rtol=2e-5, msg=name)
+    if rows > 3:
+        assert torch.all(tg.grad[1] == 0)
+    first = tg.grad.clone()
+    tg.grad = None
+    y2 = ops.pair_linear(xg, ag, bg, table=tg, index=idx_g, rowptr_by_index=rp, perm_by_index=pp)
+    (y2 * w.to(DEV)).sum().backward()
+    assert torch.equal(y2, y) and torch.equal(tg.grad, first)
+    with pytest.raises(ValueError):
+        ops.pair_linear(xg, ag, bg, table=tg, index=idx_g)  # a table that needs a gradient needs the grouping
+    with pytest.raises(ValueError):
+        ops.pair_linear(xg, ag, bg, table=tg.detach(), index=idx_g.long())

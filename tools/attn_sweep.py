@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--scenes", type=int, default=128)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--no-node-terms", action="store_true",
+                    help="time the interaction set without the per-source node rows (what the in-kernel gathers cost)")
+    ap.add_argument("--only", default=None, help="time only this edge set (agent-agent, lane-actor, interaction)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     D, H = 128, 8
@@ -47,7 +50,9 @@ def main():
     shapes = [("slot", 2), ("slot", 4), ("slot", 8), ("w1", 2), ("w1", 4), ("w1", 8), ("w2", 2), ("w2", 4), ("w2", 8),
               ("w4", 2), ("w4", 4), ("w4", 8)]
     for tag, es, node_terms in (("agent-agent", plan.agent_agent, False), ("lane-actor", plan.lane_actor, False),
-                                ("interaction", plan.interaction, True)):
+                                ("interaction", plan.interaction, not args.no_node_terms)):
+        if args.only is not None and tag != args.only:
+            continue
         n, e = es.num_dst, es.num_edges
         rp = es.rowptr.cpu()
         live = int((rp[1:] > rp[:-1]).sum())

@@ -10,16 +10,21 @@ import re
 import sys
 
 src, tag, embed_dim, scenes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-def caller(glob, split, wpn, unroll):
-    """Which module launches a kernel instance on the benchmark's workload: node terms -> interaction module, one
-    row per lane slot -> agent-agent stage (1.3 edges per row), four waves per row with eight edges in flight
-    -> lane-actor stage (52 edges per row), the remaining shapes -> the temporal encoder's last layer (21 steps
-    per agent)."""
-    if glob == "true":
+def caller(rows, split, wpn, unroll):
+    """Which module launches a kernel instance on the benchmark's workload.  `rows` is the kernel's row-source
+    template argument: 1 = node terms gathered in the kernel (the interaction module before its node rows moved
+    into the projection's epilogue), 2 = interleaved rows -> the temporal encoder's last layer; plain rows: one
+    row per lane slot -> agent-agent stage (1.3 edges per row), four waves per row with eight edges in flight ->
+    lane-actor stage (52 edges per row), the remaining shapes -> the interaction module (18 edges per row)."""
+    if rows in ("1", "true"):
         return "GlobalInteractorLayer"
+    if rows == "2":
+        return "TemporalEncoderLayer"
     if split == "true":
         return "AAEncoder"
-    return "ALEncoder" if (wpn == "4" and unroll == "8") else "TemporalEncoderLayer"
+    if wpn == "4" and unroll == "8":
+        return "ALEncoder"
+    return "GlobalInteractorLayer" if rows == "0" else "TemporalEncoderLayer"
 out = {}
 for name, scale in (("pmc_fetch_size.csv", 2 * 1024.0), ("pmc_write_size.csv", 1024.0)):
     for r in csv.DictReader(open(f"{src}/{name}")):
