@@ -278,7 +278,7 @@ def main():
                                 dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(caps, op=dist.ReduceOp.MAX)
             c = [int(v) for v in caps.tolist()]
-            spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:7]))
+            spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:]))
             trainer.edge_capacity = spec.edge_capacity
         padded = [hv.pad_batch(b, spec) for b, _ in pool]
         try:

@@ -37,6 +37,10 @@ class EdgePlan:
     interaction: EdgeSet   # agents valid at the last history step  (global_interactor.py:48-50)
     overflow: Optional[torch.Tensor] = None  # device bool: a filtered list exceeded its fixed capacity
     counts: Optional[torch.Tensor] = None    # device int32 [3]: unclamped live counts (fixed-capacity mode)
+    # the (step, agent) nodes of the agent-agent stage that are not padded, packed: the stage's output at a padded
+    # node is replaced by the padding token before anything reads it (local_encoder.py:230), so the stage is
+    # evaluated for the other nodes only
+    aa_rows: Optional[ops.RowSubset] = None
 
 
 class DistanceDropEdge:
@@ -62,6 +66,11 @@ def subgraph(subset: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tens
     src, dst, _attr, count = ops.edges_temporal(edge_index, pm, pos, 0, 1, None)
     e = int(count.item())
     return torch.stack([src[:e], dst[:e]]).long(), None
+
+
+# The agent-agent stage is evaluated for the unpadded (step, agent) nodes only; False evaluates every node, as
+# the reference does (the results that anything reads are the same either way).
+PACK_AGENT_ROWS = True
 
 
 def _pair_sets(data, T: int, n: int, local_radius: Optional[float], caps):
@@ -96,32 +105,44 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
     if from_pairs is None:
         from_pairs = bool(data.get("all_pairs", False)) and "scene_range" in data
     la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
+    # nodes (t, n) of the agent-agent stage that are not padded, t-major
+    valid = ~data["padding_mask"][:, :T].t().reshape(-1) if (PACK_AGENT_ROWS and n > 0) else None
+    # (read back with the edge counts when no capacities are given; a fixed-capacity plan never needs it)
+    live_rows = valid.sum(dtype=torch.int32).view(1) if (valid is not None and caps is None) else None
+    row_cap = min(int(caps[3]), T * n) if (caps is not None and len(caps) > 3) else T * n
     if from_pairs:
         e0 = int(data["edge_index"].shape[1])
         pair_caps = (min(int(caps[0]), e0 * T), min(int(caps[2]), e0)) if caps is not None else (e0 * T, e0)
         aa, gi = _pair_sets(data, T, n, local_radius, pair_caps)
         if caps is None:
-            counts = torch.cat([aa[4], la[3], gi[4]]).cpu()  # the only host synchronisation of the forward pass
-            c_aa, c_la, c_gi = (int(c) for c in counts)
+            # the only host synchronisation of the forward pass
+            counts = torch.cat([aa[4], la[3], gi[4]] + ([live_rows] if valid is not None else [])).cpu()
+            c_aa, c_la, c_gi = (int(c) for c in counts[:3])
             sets = [EdgeSet(T * n, T * n, aa[1][:c_aa], aa[2][:c_aa], aa[3][:c_aa], aa[0], None, aa[1][:c_aa], aa[2][:c_aa]),
                     ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n),
                     EdgeSet(n, n, gi[1][:c_gi], gi[2][:c_gi], gi[3][:c_gi], gi[0], None, gi[1][:c_gi], gi[2][:c_gi])]
-            return EdgePlan(*sets)
+            rows = ops.row_subset(valid, None, sets[0].rowptr, int(counts[3])) if valid is not None else None
+            return EdgePlan(*sets, aa_rows=rows)
         c_la = min(int(caps[1]), int(la[0].shape[0]))
         sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4].clamp(max=pair_caps[0])),
                 ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3].clamp(max=c_la)),
                 EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4].clamp(max=pair_caps[1]))]
         counts = torch.cat([aa[4], la[3], gi[4]])
         overflow = (aa[4] > pair_caps[0]) | (la[3] > c_la) | (gi[4] > pair_caps[1])
-        return EdgePlan(*sets, overflow=overflow.view(()), counts=counts)
+        rows = ops.row_subset(valid, row_cap, sets[0].rowptr) if valid is not None else None
+        if rows is not None:
+            overflow = overflow | rows.overflow
+        return EdgePlan(*sets, overflow=overflow.view(()), counts=counts, aa_rows=rows)
     aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
     gi = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], T - 1, 1, None)
     shapes = ((T * n, T * n), (num_lanes, n), (n, n))
     if caps is None:
-        counts = torch.cat([aa[3], la[3], gi[3]]).cpu()  # the only host synchronisation of the forward pass
+        # the only host synchronisation of the forward pass
+        counts = torch.cat([aa[3], la[3], gi[3]] + ([live_rows] if valid is not None else [])).cpu()
         sets = [ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd)
-                for lst, c, (ns, nd) in zip((aa, la, gi), (int(c) for c in counts), shapes)]
-        return EdgePlan(*sets)
+                for lst, c, (ns, nd) in zip((aa, la, gi), (int(c) for c in counts[:3]), shapes)]
+        rows = ops.row_subset(valid, None, sets[0].rowptr, int(counts[3])) if valid is not None else None
+        return EdgePlan(*sets, aa_rows=rows)
     caps = [min(int(c), int(lst[0].shape[0])) for c, lst in zip(caps, (aa, la, gi))]
     sets, overflow = [], None
     for lst, c, (ns, nd) in zip((aa, la, gi), caps, shapes):
@@ -129,7 +150,10 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
         over = lst[3] > c
         overflow = over if overflow is None else overflow | over
     counts = torch.cat([aa[3], la[3], gi[3]])
-    return EdgePlan(*sets, overflow=overflow.view(()), counts=counts)
+    rows = ops.row_subset(valid, row_cap, sets[0].rowptr) if valid is not None else None
+    if rows is not None:
+        overflow = overflow | rows.overflow
+    return EdgePlan(*sets, overflow=overflow.view(()), counts=counts, aa_rows=rows)
 
 
 def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
@@ -195,14 +219,16 @@ class _EdgeAttentionBase(nn.Module):
         return [(self.lin_k, self.lin_v), (self.lin_hh, self.lin_self)]
 
     def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet,
-                           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           residual: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None
+                           ) -> torch.Tensor:
         """``[residual +]`` message (Q.K, segment softmax, weighting) + aggregate + update + out_proj +
         dropout for per-edge embeddings already in CSR order (``local_encoder.py:174-188,197-199`` /
         ``:364-379,391-394``)."""
         kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
         q = _linear(center, self.lin_q)
-        agg = ops.seg_attn(q, kv, edges.rowptr, self.num_heads, self.attn_drop.p, self.training,
-                           tag=type(self).__name__, padded=edges.count is not None)
+        # `rowptr`: the edge set's row pointer re-indexed to packed target rows (`center` then holds those rows)
+        agg = ops.seg_attn(q, kv, edges.rowptr if rowptr is None else rowptr, self.num_heads, self.attn_drop.p,
+                           self.training, tag=type(self).__name__, padded=edges.count is not None)
         if residual is not None:
             return ops.gated_update_tail(agg, center, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
                                          self.proj_drop.p, self.proj_drop.training)
@@ -230,22 +256,35 @@ class AAEncoder(_EdgeAttentionBase):
 
     def forward(self, x: torch.Tensor, t: Optional[int], edge_index: Optional[torch.Tensor],
                 edge_attr: Optional[torch.Tensor], bos_mask: torch.Tensor, rotate_mat: Optional[torch.Tensor] = None,
-                size=None, edges: Optional[EdgeSet] = None) -> torch.Tensor:
+                size=None, edges: Optional[EdgeSet] = None, rows: Optional[ops.RowSubset] = None) -> torch.Tensor:
         """``parallel`` modules (or ``t is None``) take x [T*N, 2], bos_mask [N, T] and node ids
         ``t*N + n``; otherwise x [N, 2], an integer ``t`` and bos_mask [N].  ``edges`` may carry the
-        already grouped edge set instead of ``edge_index`` / ``edge_attr``."""
+        already grouped edge set instead of ``edge_index`` / ``edge_attr``.  With ``rows`` (batched form, GPU) the
+        stage is evaluated for that subset of the T*N nodes only and the result holds its packed rows
+        [rows.capacity, D]; nodes outside the subset must own no edges."""
         T = self.historical_steps
         batched = self.parallel or t is None
+        rowptr = None
+        if rows is not None and not (batched and edges is not None and rows.rowptr is not None):
+            raise ValueError("a row subset goes with the batched form and a grouped edge set")
         if batched:
             n = x.shape[0] // T
             xv = x.view(T, n, -1)
             if rotate_mat is not None:  # row vector times the agent's 2x2, written out (no batched GEMM)
                 xv = xv[..., 0:1] * rotate_mat[:, 0, :] + xv[..., 1:2] * rotate_mat[:, 1, :]
-            center = self.center_embed(xv)
-            if ops.step_tokens_supported(center, T):
-                center = ops.masked_step_tokens(center, bos_mask.t(), self.bos_token).reshape(x.shape[0], -1)
+            if rows is not None:
+                step = torch.div(rows.rows, n, rounding_mode="floor")
+                center = self.center_embed(xv.reshape(T * n, -1).index_select(0, rows.rows))
+                center = ops.masked_row_tokens(center, bos_mask.t().reshape(-1).index_select(0, rows.rows), step,
+                                               self.bos_token)
+                rowptr = rows.rowptr
             else:
-                center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2), center).reshape(x.shape[0], -1)
+                center = self.center_embed(xv)
+                if ops.step_tokens_supported(center, T):
+                    center = ops.masked_step_tokens(center, bos_mask.t(), self.bos_token).reshape(x.shape[0], -1)
+                else:
+                    center = torch.where(bos_mask.t().unsqueeze(-1), self.bos_token.unsqueeze(-2),
+                                         center).reshape(x.shape[0], -1)
             rot_mod = n
         else:
             xr = x if rotate_mat is None else x[:, 0:1] * rotate_mat[:, 0, :] + x[:, 1:2] * rotate_mat[:, 1, :]
@@ -256,14 +295,17 @@ class AAEncoder(_EdgeAttentionBase):
             edges = _edge_set_from_coo(edge_index, edge_attr, x.shape[0], x.shape[0])
         # the residual additions are part of the last launch of each block
         normed, center = ops.layer_norm_residual(center, self.norm1)
-        center = self._mha_block(normed, x, edges, rotate_mat, rot_mod, residual=center)
+        center = self._mha_block(normed, x, edges, rotate_mat, rot_mod, residual=center, rowptr=rowptr)
         return _pre_norm_ffn(center, self.norm2, self.mlp)
 
     def _mha_block(self, center: torch.Tensor, x: torch.Tensor, edges: EdgeSet, rotate_mat: Optional[torch.Tensor],
-                   rot_mod: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   rot_mod: int, residual: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None
+                   ) -> torch.Tensor:
+        # the per-edge features are looked up by the edges' own node ids in the full node set `x`, whether or not
+        # `center` holds packed rows
         feat, _src, _dst = ops.edge_gather_rotate(x, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
                                                   edges.perm, rot_mod, edges.count)
-        return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges, residual)
+        return self._attend_and_update(center, self.nbr_embed.forward_packed(feat), edges, residual, rowptr)
 
 
 class ALEncoder(_EdgeAttentionBase):
@@ -460,8 +502,13 @@ class TemporalEncoder(nn.Module):
             nn.init.normal_(token, mean=0.0, std=0.02)
         self.apply(init_weights)
 
-    def forward(self, x: torch.Tensor, padding_mask: torch.Tensor) -> torch.Tensor:
-        if ops.step_tokens_supported(x, x.shape[0] + 1):
+    def forward(self, x: torch.Tensor, padding_mask: torch.Tensor, rows: Optional[ops.RowSubset] = None
+                ) -> torch.Tensor:
+        """x [T, N, D]; or, with ``rows`` (the unpadded (step, agent) nodes, packed), x [rows.capacity, D]."""
+        if rows is not None:
+            x = ops.expand_rows_with_tokens(x, rows, padding_mask.t(), self.padding_token.squeeze(1))
+            x = ops.append_token_add_steps(x, self.cls_token.view(-1), self.pos_embed.squeeze(1))
+        elif ops.step_tokens_supported(x, x.shape[0] + 1):
             x = ops.masked_step_tokens(x, padding_mask.t(), self.padding_token.squeeze(1))
             x = ops.append_token_add_steps(x, self.cls_token.view(-1), self.pos_embed.squeeze(1))
         else:
@@ -500,10 +547,14 @@ class LocalEncoder(nn.Module):
             plan = build_edge_plan(data, T, self.local_radius)
             data["edge_plan"] = plan
         x_all = data["x"][:, :T].transpose(0, 1).reshape(T * n, -1)
+        rows = plan.aa_rows
+        if rows is not None and not (x_all.is_cuda and self.aa_encoder.embed_dim <= 128 and T + 1 <= 32):
+            rows = None
         out = self.aa_encoder(x=x_all, t=None, edge_index=None, edge_attr=None, bos_mask=data["bos_mask"],
-                              rotate_mat=data["rotate_mat"], edges=plan.agent_agent)
-        out = out.view(T, n, -1)
-        out = self.temporal_encoder(x=out, padding_mask=data["padding_mask"][:, :T])
+                              rotate_mat=data["rotate_mat"], edges=plan.agent_agent, rows=rows)
+        if rows is None:
+            out = out.view(T, n, -1)
+        out = self.temporal_encoder(x=out, padding_mask=data["padding_mask"][:, :T], rows=rows)
         out = self.al_encoder(x=(data["lane_vectors"], out), edge_index=None, edge_attr=None,
                               is_intersections=data["is_intersections"], turn_directions=data["turn_directions"],
                               traffic_controls=data["traffic_controls"], rotate_mat=data["rotate_mat"],

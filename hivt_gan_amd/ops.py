@@ -1811,6 +1811,121 @@ def append_token_add_steps(x: torch.Tensor, last: torch.Tensor, per_step: torch.
     return _AppendTokenAddSteps.apply(x, last, per_step)
 
 
+# --------------------------------------------------------------------------------------------
+# Row subsets: a stage that is evaluated for some rows of a [steps * agents] node set only
+# --------------------------------------------------------------------------------------------
+@dataclass
+class RowSubset:
+    """The live rows of a node set, packed to the front of ``capacity`` rows.
+
+    ``rows`` [capacity] int32: node id of every packed row (entries at or beyond ``count`` repeat a valid id, so
+    whatever is gathered through them is finite; nothing reads their results).  ``new_id`` [num_rows] int32: packed
+    position of a node (nodes outside the subset: some position inside the packed range).  ``rowptr`` [capacity + 1]:
+    the CSR row pointer of an edge set over the full node set, re-indexed to packed rows (rows outside the subset
+    must own no edges; packed rows beyond ``count`` own none)."""
+    rows: torch.Tensor
+    new_id: torch.Tensor
+    live: torch.Tensor           # [capacity] bool: packed row < count
+    count: torch.Tensor          # 0-d int32 on the device
+    capacity: int
+    num_rows: int
+    rowptr: Optional[torch.Tensor] = None
+    overflow: Optional[torch.Tensor] = None  # 0-d bool: more live rows than capacity
+
+
+def row_subset(valid: torch.Tensor, capacity: Optional[int] = None, rowptr: Optional[torch.Tensor] = None,
+               count_hint: Optional[int] = None) -> RowSubset:
+    """Packs the rows with ``valid`` (bool [M]) in ascending order.  Without ``capacity`` the packed size is the
+    live count (``count_hint`` if the caller has already read it back, else one read-back here); with it nothing
+    is read back, the packed arrays have ``capacity`` rows and ``overflow`` tells whether the live rows fit."""
+    _need_gpu(valid)
+    m = int(valid.shape[0])
+    dev = valid.device
+    pos = torch.cumsum(valid, 0, dtype=torch.int32)          # inclusive count of live rows up to each row
+    count = pos[-1] if m > 0 else torch.zeros((), dtype=torch.int32, device=dev)
+    if capacity is None:
+        capacity = int(count_hint) if count_hint is not None else int(count.item())
+    capacity = max(int(capacity), 1)
+    new_id = pos - 1
+    ids = torch.arange(m, dtype=torch.int32, device=dev)
+    # slot `capacity + 1` swallows the rows outside the subset (and live rows that do not fit)
+    slot = torch.where(valid & (new_id < capacity), new_id, capacity + 1).long()
+    buf = torch.full((capacity + 2,), m, dtype=torch.int32, device=dev)
+    buf.scatter_(0, slot, ids)
+    packed_rowptr = rowptr.index_select(0, buf[:capacity + 1]) if rowptr is not None else None
+    live = torch.arange(capacity, dtype=torch.int32, device=dev) < count
+    # entries beyond the live rows repeat the first live row: gathers through them stay finite
+    first = buf[0].clamp(max=max(m - 1, 0))
+    rows = torch.where(live, buf[:capacity], first)
+    return RowSubset(rows, new_id.clamp_(min=0, max=capacity - 1), live, count, capacity, m, packed_rowptr,
+                     (count > capacity).view(()))
+
+
+class _MaskedRowTokens(torch.autograd.Function):
+    """``where(mask[:, None], token[code], x)`` for x [M, D], mask [M] bool, code [M] int32, token [R, D]; the
+    token's gradient is a per-code row sum in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, x, mask, code, token):
+        out = torch.where(mask.unsqueeze(-1), token.index_select(0, code), x)
+        ctx.save_for_backward(mask, code)
+        ctx.codes = int(token.shape[0])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        mask, code = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.where(mask.unsqueeze(-1), torch.zeros((), dtype=dy.dtype, device=dy.device), dy) \
+            if ctx.needs_input_grad[0] else None
+        dtoken = _rowsum_by_code(dy, torch.where(mask, code, -1), ctx.codes) if ctx.needs_input_grad[3] else None
+        return dx, None, None, dtoken
+
+
+def masked_row_tokens(x: torch.Tensor, mask: torch.Tensor, code: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
+    """Rows with ``mask`` replaced by ``token[code]`` (x [M, D], code int32 [M] in [0, R), token [R, D], R <= 32)."""
+    return _MaskedRowTokens.apply(x, mask, code, token)
+
+
+class _ExpandRowsTokens(torch.autograd.Function):
+    """Packed rows back on the full [T, N] node set: node (t, n) takes ``token[t]`` where ``mask[t, n]`` and packed
+    row ``new_id[t * N + n]`` elsewhere (``models/local_encoder.py:230`` applied to a stage that was evaluated for
+    the unmasked nodes only)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, new_id, live, mask, token):
+        t, n = mask.shape
+        mask = mask.contiguous()
+        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x.index_select(0, new_id).view(t, n, -1))
+        ctx.save_for_backward(rows, live, mask)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        rows, live, mask = ctx.saved_tensors
+        t, n, d = dy.shape
+        dy = dy.contiguous().view(t * n, d)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.where(live.unsqueeze(-1), dy.index_select(0, rows),
+                             torch.zeros((), dtype=dy.dtype, device=dy.device))
+        dtoken = None
+        if ctx.needs_input_grad[5]:
+            codes = torch.where(mask.reshape(-1), _codes(t, n, dy.device), -1)
+            dtoken = _rowsum_by_code(dy, codes, t)
+        return dx, None, None, None, None, dtoken
+
+
+def expand_rows_with_tokens(x: torch.Tensor, subset: RowSubset, mask: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
+    """[T, N, D] from packed rows ``x`` [capacity, D] of ``subset`` (the nodes with ``~mask``) and one token row per
+    step for the masked nodes; mask [T, N] bool, token [T, D]."""
+    if subset.num_rows != mask.numel() or x.shape[0] != subset.capacity:
+        raise ValueError("expand_rows_with_tokens: the subset does not belong to this node set")
+    return _ExpandRowsTokens.apply(x, subset.rows, subset.new_id, subset.live, mask, token)
+
+
 def step_guards(nan_check: Optional[torch.Tensor], finite_check: Optional[torch.Tensor],
                 extra: Optional[torch.Tensor] = None) -> torch.Tensor:
     """0-d device bool: ``nan_check`` holds a NaN, ``finite_check`` a NaN or an infinity, or ``extra`` (a

@@ -248,12 +248,13 @@ class GanTrainer:
     """Owns the optimizers, LR schedule and gradient buckets of one rank.
 
     ``edge_capacity`` (three integers: agent-agent over all history steps, lane-actor, last-step
-    interaction) switches the step to the read-back-free mode described in the module docstring.  A
-    batch whose filtered edge lists do not fit is discarded on the device and counted in
-    ``overflowed_steps()``."""
+    interaction; optionally a fourth: unpadded (step, agent) nodes of the agent-agent stage, without which
+    that stage is evaluated for every node) switches the step to the read-back-free mode described in the
+    module docstring.  A batch whose filtered edge lists or live nodes do not fit is discarded on the device
+    and counted in ``overflowed_steps()``."""
 
     def __init__(self, model: HiVT, distributed: Optional[bool] = None,
-                 edge_capacity: Optional[Tuple[int, int, int]] = None, overlap: Optional[bool] = None,
+                 edge_capacity: Optional[Tuple[int, ...]] = None, overlap: Optional[bool] = None,
                  sync_logs: bool = True) -> None:
         self.model = model
         self.distributed = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
@@ -299,11 +300,14 @@ class GanTrainer:
         from .local_encoder import build_edge_plan
         batches = list(batches)
         spec = BatchSpec.covering(batches)
-        worst = [0, 0, 0]
+        worst = [0, 0, 0, 0]
         for b in batches:
             plan = build_edge_plan(b, model.historical_steps, model.local_encoder.local_radius)
             for i, es in enumerate((plan.agent_agent, plan.lane_actor, plan.interaction)):
                 worst[i] = max(worst[i], es.num_edges)
+            # fourth capacity: unpadded (step, agent) nodes, the rows the agent-agent stage is evaluated for
+            worst[3] = max(worst[3], plan.aa_rows.capacity if plan.aa_rows is not None
+                           else model.historical_steps * int(b.num_nodes))
         spec.edge_capacity = tuple(int(-(-int(w * slack + 1) // multiple) * multiple) for w in worst)
         return spec
 

@@ -351,3 +351,65 @@ def test_packed_parameters_change_nothing_but_the_copies():
     assert not is_view(moved.local_encoder.aa_encoder.lin_k, moved.local_encoder.aa_encoder.lin_v)
     y3, _, g3 = run(moved)
     assert torch.equal(y3, y0) and all(torch.equal(g3[k], g0[k]) for k in g0)
+
+
+def test_agent_stage_on_unpadded_nodes_only_changes_nothing_observable():
+    """The agent-agent stage evaluated for the unpadded (step, agent) nodes only: a padded node's result is
+    replaced by the padding token before anything reads it (models/local_encoder.py:230) and receives no
+    gradient, so outputs are the same (bit for bit while all other launches keep their shapes) and parameter
+    gradients agree to summation order -- with the packed size read back and with a fixed row capacity."""
+    from hivt_gan_amd import local_encoder as le
+    model = small_model()
+    batch = hv.make_batch(6, first_index=700).to(DEV)
+    hist = batch["padding_mask"][:, :20]
+    assert 0.2 < float(hist.float().mean()) < 0.8  # the synthetic scenes do pad a good part of the history
+    spec = hv.GanTrainer.calibrate(model, [batch])
+    assert len(spec.edge_capacity) == 4 and spec.edge_capacity[3] < 20 * spec.num_nodes
+    results = {}
+    try:
+        for mode in ("every node", "packed", "packed, fixed capacity"):
+            le.PACK_AGENT_ROWS = mode != "every node"
+            data = hv.pad_batch(batch, spec) if mode.endswith("capacity") else batch.clone()
+            if not mode.endswith("capacity"):
+                data["edge_capacity"] = None
+            model.zero_grad(set_to_none=True)
+            y_hat, pi = model(data)
+            plan = data["edge_plan"]
+            assert (plan.aa_rows is not None) == le.PACK_AGENT_ROWS
+            n = int(batch.num_nodes)
+            (y_hat[:, :n, :, :2].square().sum() + pi[:n].square().sum()).backward()  # the real agents only
+            results[mode] = (y_hat[:, :n].detach().clone(), pi[:n].detach().clone(),
+                             {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+            if le.PACK_AGENT_ROWS:
+                live = int((~hist).sum())
+                assert int(plan.aa_rows.count) == live
+                assert plan.aa_rows.capacity == (spec.edge_capacity[3] if mode.endswith("capacity") else live)
+    finally:
+        le.PACK_AGENT_ROWS = True
+    y0, pi0, g0 = results["every node"]
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for mode in ("packed", "packed, fixed capacity"):
+        y1, pi1, g1 = results[mode]
+        if mode == "packed":  # same launches everywhere else: the very same numbers
+            assert torch.equal(y1, y0) and torch.equal(pi1, pi0), mode
+        else:  # fixed shapes pad every stage (other launch shapes, other summation orders): inert, not bit-identical
+            assert rel_err(y1, y0) < 1e-5 and rel_err(pi1, pi0) < 1e-5, mode
+        assert g1.keys() == g0.keys()
+        for k, g in g0.items():
+            err = float((g1[k] - g).abs().max())
+            assert err <= 1e-5 * max(float(g.abs().max()), 1e-3 * gmax), (mode, k, err)
+
+
+def test_row_capacity_overflow_discards_the_batch():
+    batch = hv.make_batch(4, first_index=520).to(DEV)
+    model = small_model()
+    spec = hv.GanTrainer.calibrate(model, [batch])
+    tight = spec.edge_capacity[:3] + (spec.edge_capacity[3] // 4,)
+    tr = hv.GanTrainer(model, edge_capacity=tight)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    logs = tr.step(batch.clone())
+    assert float(logs["skipped"]) == 1.0 and tr.overflowed_steps() == 1
+    for k, v in model.named_parameters():
+        assert torch.equal(v, before[k]), k
+    ok = hv.GanTrainer(model, edge_capacity=spec.edge_capacity[:3])  # no row capacity: every node is evaluated
+    assert float(ok.step(batch.clone())["skipped"]) == 0.0

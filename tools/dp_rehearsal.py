@@ -102,7 +102,7 @@ def worker(rank, world, port, steps):
     caps = caps.to(dev) if backend == "nccl" else caps
     dist.all_reduce(caps, op=dist.ReduceOp.MAX)
     c = [int(v) for v in caps.tolist()]
-    spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:7]))
+    spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:]))
     trainer.edge_capacity = spec.edge_capacity
     for b, y in zip(pool, ys):
         b["y"] = y
