@@ -317,13 +317,13 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) 
 // not depend on scheduling.  One block covers COLS columns; each thread sums one slice of one column.
 // Columns at or beyond `split` go to out1[c - split] (two result vectors from one partial buffer).
 template <int COLS, int SLICES>
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
-                                                          int C, float* __restrict__ out, int split,
-                                                          float* __restrict__ out1, int accumulate) {
+__device__ __forceinline__ void reduce_rows_body(float* part /*[SLICES * COLS]*/, int col_block,
+                                                 const float* __restrict__ partial, int R, int64_t pitch, int C,
+                                                 float* __restrict__ out, int split, float* __restrict__ out1,
+                                                 int accumulate) {
   static_assert(COLS * SLICES == 256, "one thread per (column, slice)");
-  __shared__ float part[SLICES][COLS];
   const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
-  const int c = blockIdx.x * COLS + col;
+  const int c = col_block * COLS + col;
   const int per = (R + SLICES - 1) / SLICES;
   const int r0 = min(R, sl * per), r1 = min(R, r0 + per);
   float s = 0.0f;
@@ -338,15 +338,54 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
     for (; r < r1; ++r) s += partial[(int64_t)r * pitch + c];
   }
-  part[sl][col] = s;
+  part[sl * COLS + col] = s;
   __syncthreads();
   if (sl == 0 && c < C) {
-    float t = part[0][col];
+    float t = part[col];
 #pragma unroll
-    for (int i = 1; i < SLICES; ++i) t += part[i][col];
+    for (int i = 1; i < SLICES; ++i) t += part[i * COLS + col];
     float* dst = c < split ? out + c : out1 + (c - split);
     *dst = accumulate ? *dst + t : t;  // accumulate: the sum is added to what the output holds
   }
+}
+
+template <int COLS, int SLICES>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, int R, int64_t pitch,
+                                                          int C, float* __restrict__ out, int split,
+                                                          float* __restrict__ out1, int accumulate) {
+  __shared__ float part[256];
+  reduce_rows_body<COLS, SLICES>(part, (int)blockIdx.x, partial, R, pitch, C, out, split, out1, accumulate);
+}
+
+// Many such reductions in one launch (the per-block partial sums that the LayerNorm backward calls of a whole
+// backward pass left behind): workgroup b serves one column block of the entry whose block range holds b, with
+// the slicing launch_reduce_rows would pick for that entry, so the sums are the same bit for bit.
+constexpr int kRowsGroupMax = 48;
+
+struct RowsEntry {
+  const float* partial;
+  float* out;
+  float* out1;
+  int64_t pitch;
+  int32_t R, C, split, accumulate;
+};
+
+struct RowsGroup {
+  RowsEntry e[kRowsGroupMax];
+  int32_t first_block[kRowsGroupMax + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void reduce_rows_group_kernel(const RowsGroup g) {
+  __shared__ float part[256];
+  int i = 0;
+  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
+  const RowsEntry& e = g.e[i];
+  const int cb = (int)blockIdx.x - g.first_block[i];
+  if (e.R >= 64)
+    reduce_rows_body<16, 16>(part, cb, e.partial, e.R, e.pitch, e.C, e.out, e.split, e.out1, e.accumulate);
+  else
+    reduce_rows_body<64, 4>(part, cb, e.partial, e.R, e.pitch, e.C, e.out, e.split, e.out1, e.accumulate);
 }
 
 // Many partial rows: sixteen slices of sixteen-column blocks shorten each thread's serial chain.
@@ -1091,12 +1130,15 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
                            size_t workspace_bytes, hivt_stream_t stream) {
   const char* what = "hivt_ln_bwd";
   HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128, HIVT_ERR_ARG, "%s: N must be in [1,128] (N=%d)", what, N);
-  HIVT_REQUIRE(dgamma && dbeta, HIVT_ERR_ARG, "%s: null gradient output", what);
+  HIVT_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), HIVT_ERR_ARG, "%s: dgamma and dbeta go together", what);
+  const bool leave_partials = dgamma == nullptr;  // the caller sums workspace[hivt_ln_bwd_partial_rows(M)][2][N] itself
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) {
-    zero_words(dgamma, N, s);
-    zero_words(dbeta, N, s);
-    HIVT_CHECK_LAUNCH(what);
+    if (!leave_partials) {
+      zero_words(dgamma, N, s);
+      zero_words(dbeta, N, s);
+      HIVT_CHECK_LAUNCH(what);
+    }
     return HIVT_OK;
   }
   HIVT_REQUIRE(dy && z && stats && gamma && beta && dz, HIVT_ERR_ARG, "%s: null pointer", what);
@@ -1113,9 +1155,44 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
     hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
                        beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
   HIVT_CHECK_LAUNCH(what);
+  if (leave_partials) return HIVT_OK;
   // partial is [blocks][2][N]: one reduction over the 2N columns, first half -> dgamma, second -> dbeta
   launch_reduce_rows(s, partial, (int)blocks, (int64_t)2 * N, 2 * N, dgamma, N, dbeta);
   HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" size_t hivt_ln_bwd_partial_rows(int64_t M) { return M > 0 ? (size_t)ln_bwd_blocks(M) : 0; }
+
+extern "C" int hivt_reduce_rows_group(const int64_t* items, int32_t count, hivt_stream_t stream) {
+  const char* what = "hivt_reduce_rows_group";
+  HIVT_REQUIRE(count >= 0 && (count == 0 || items != nullptr), HIVT_ERR_ARG, "%s: bad item list", what);
+  hipStream_t s = (hipStream_t)stream;
+  for (int32_t base = 0; base < count; base += kRowsGroupMax) {
+    RowsGroup g{};
+    g.count = std::min<int32_t>(kRowsGroupMax, count - base);
+    int32_t blocks = 0;
+    for (int32_t i = 0; i < g.count; ++i) {
+      const int64_t* it = items + (int64_t)(base + i) * 8;
+      RowsEntry& e = g.e[i];
+      e.partial = reinterpret_cast<const float*>(it[0]);
+      e.R = (int32_t)it[1];
+      e.pitch = it[2];
+      e.C = (int32_t)it[3];
+      e.out = reinterpret_cast<float*>(it[4]);
+      e.split = (int32_t)it[5];
+      e.out1 = reinterpret_cast<float*>(it[6]);
+      e.accumulate = (int32_t)it[7];
+      HIVT_REQUIRE(e.R >= 0 && e.C > 0 && e.pitch >= e.C && e.out != nullptr && (e.R == 0 || e.partial != nullptr) &&
+                       e.split >= 0 && (e.split >= e.C || e.out1 != nullptr),
+                   HIVT_ERR_ARG, "%s: item %d is malformed", what, base + i);
+      g.first_block[i] = blocks;
+      blocks += e.R >= 64 ? (e.C + 15) / 16 : (e.C + 63) / 64;
+    }
+    g.first_block[g.count] = blocks;
+    hipLaunchKernelGGL(reduce_rows_group_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g);
+    HIVT_CHECK_LAUNCH(what);
+  }
   return HIVT_OK;
 }
 

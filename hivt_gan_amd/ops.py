@@ -625,23 +625,34 @@ class deferred_weight_grads:
     """Context manager; see above.  Not re-entrant across threads: one training step at a time."""
 
     def __enter__(self):
-        global _deferred
-        self._prev = _deferred
-        _deferred = []
+        global _deferred, _deferred_rows
+        self._prev = (_deferred, _deferred_rows)
+        _deferred, _deferred_rows = [], []
         return self
 
     def __exit__(self, *exc):
-        global _deferred
+        global _deferred, _deferred_rows
         try:
             if exc[0] is None:
                 flush_weight_grads()
         finally:
-            _deferred = self._prev
+            _deferred, _deferred_rows = self._prev
         return False
 
 
 def flush_weight_grads() -> None:
     """Issues the collected weight gradients (runs by itself at the end of every backward pass)."""
+    rows = _deferred_rows
+    if rows:
+        flat, keep, dev = [], [], rows[0][1]
+        for item, _, part in rows:
+            flat += item
+            keep.append(part)
+        count = len(rows)
+        del rows[:]
+        _lib.call("hivt_reduce_rows_group", (ctypes.c_int64 * len(flat))(*flat), count,
+                  torch._C._cuda_getCurrentRawStream(dev.index))
+        del keep
     queue = _deferred
     if not queue:
         return
@@ -668,7 +679,7 @@ def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int,
     dw = torch.empty(n, k, dtype=torch.float32, device=dev)
     db = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
     if leaves and _deferred is not None and m > 0:
-        if not _deferred:
+        if not _deferred and not _deferred_rows:
             torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
         # addresses, not tensors, of the results: autograd takes a gradient over only while it holds the one
         # reference to it
@@ -678,6 +689,33 @@ def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int,
     ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
     _lib.call("hivt_linear_wgrad", _p(g), g_ld, _p(x), x_ld, m, n, k, _p(dw), _p(db), _p(ws), ws.numel(), _stream(g))
     return dw, db
+
+
+_deferred_rows: Optional[list] = None  # LayerNorm partial sums waiting for their one reduction (same scope)
+
+
+def _ln_backward(dy2, z, z_ld, stats, gamma, beta, relu: int, m: int, n: int, add2, dz, stream, leaves: bool):
+    """``hivt_ln_bwd``: fills ``dz`` and returns ``(dgamma, dbeta)``.  With ``leaves`` (gamma and beta are leaves of
+    the graph) inside ``deferred_weight_grads()`` the kernel's partial sums stay in a buffer of their own and one
+    grouped reduction at the end of the backward pass fills the two gradients of every LayerNorm."""
+    dev = dz.device
+    dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+    add_ld = add2.stride(0) if add2 is not None else 0
+    if leaves and _deferred is not None and m > 0:
+        rows = _lib.query("hivt_ln_bwd_partial_rows", m)
+        part = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", m, n) // 4, dtype=torch.float32, device=dev)
+        _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
+                  _p(add2), add_ld, _p(dz), dz.stride(0), None, None, _p(part), part.numel() * 4, stream)
+        if not _deferred and not _deferred_rows:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+        _deferred_rows.append(([part.data_ptr(), rows, 2 * n, 2 * n, dgamma.data_ptr(), n, dbeta.data_ptr(), 0], dev,
+                               part))
+        return dgamma, dbeta
+    ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
+    _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
+              _p(add2), add_ld, _p(dz), dz.stride(0), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), stream)
+    return dgamma, dbeta
 
 
 class _FusedLinear(torch.autograd.Function):
@@ -728,6 +766,7 @@ class _FusedLinear(torch.autograd.Function):
         ctx.res_leaf = residual is not None and residual.is_leaf
         ctx.add_leaf = add is not None and add.is_leaf
         ctx.param_leaves = _all_leaves(weight, bias)
+        ctx.norm_leaves = ln and _all_leaves(gamma, beta)
         return y.view(*lead, n)
 
     @staticmethod
@@ -743,11 +782,7 @@ class _FusedLinear(torch.autograd.Function):
         dgamma = dbeta = None
         if ln:
             dz = torch.empty(m, n, dtype=torch.float32, device=dev)
-            dgamma = torch.empty(n, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(n, dtype=torch.float32, device=dev)
-            ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
-            _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), n, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
-                      None, 0, _p(dz), n, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+            dgamma, dbeta = _ln_backward(dy2, z, n, stats, gamma, beta, int(relu), m, n, None, dz, s, ctx.norm_leaves)
         elif dropout_p > 0.0:
             dz = torch.empty(m, n, dtype=torch.float32, device=dev)
             _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), _p(y_relu), n, int(relu), dropout_p, seed,
@@ -904,6 +939,7 @@ class _LayerNorm(torch.autograd.Function):
                   _stream(x))
         ctx.save_for_backward(x2, stats, gamma_c, beta_c)
         ctx.lead = tuple(lead)
+        ctx.norm_leaves = _all_leaves(gamma, beta)
         ctx.set_materialize_grads(False)
         return y.view(*lead, n), x.view_as(x)
 
@@ -918,12 +954,8 @@ class _LayerNorm(torch.autograd.Function):
         dy2 = _rows2(dy)
         add2 = _rows2(dres) if dres is not None else None
         dx = torch.empty(m, n, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(n, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(n, dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
-        _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, n,
-                  _p(add2), add2.stride(0) if add2 is not None else 0, _p(dx), n, _p(dgamma), _p(dbeta), _p(ws),
-                  ws.numel(), _stream(x2))
+        dgamma, dbeta = _ln_backward(dy2, x2, x2.stride(0), stats, gamma, beta, 0, m, n, add2, dx, _stream(x2),
+                                     ctx.norm_leaves)
         return dx.view(*ctx.lead, n), dgamma, dbeta, None
 
 
@@ -1494,6 +1526,7 @@ class _PreNormFeedForward(torch.autograd.Function):
         ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, h, w1c, w2c, DEVICE_SEED if p2 > 0.0 else None)
         ctx.cfg = (tuple(lead), float(p1), float(p2), int(seed2))
         ctx.param_leaves = _all_leaves(w1, b1, w2, b2)
+        ctx.norm_leaves = _all_leaves(gamma, beta)
         return y.view(*lead, d)
 
     @staticmethod
@@ -1513,7 +1546,6 @@ class _PreNormFeedForward(torch.autograd.Function):
             dz2 = dy2
         # second Linear: weight gradient, then the data gradient gated by the ReLU / dropout of its input
         dw2, db2 = _weight_grad(dz2, dz2.stride(0), h, hdim, m, d, hdim, dev, leaves=ctx.param_leaves)
-        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, d), dev)
         dz1 = torch.empty(m, hdim, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
                   1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
@@ -1523,10 +1555,7 @@ class _PreNormFeedForward(torch.autograd.Function):
         _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0, _p(dxn), d, s)
         # LayerNorm, plus the residual route's gradient (dy itself)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(d, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_ln_bwd", _p(dxn), d, _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, d, _p(dy2),
-                  dy2.stride(0), _p(dx), d, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), s)
+        dgamma, dbeta = _ln_backward(dxn, x2, x2.stride(0), stats, gamma, beta, 0, m, d, dy2, dx, s, ctx.norm_leaves)
         return dx.view(*lead, d), dgamma, dbeta, None, dw1, db1, dw2, db2, None, None, None, None
 
 
@@ -1582,6 +1611,7 @@ class _PreNormTemporalAttention(torch.autograd.Function):
                               DEVICE_SEED if (p_attn > 0.0 or p_out > 0.0) else None)
         ctx.cfg = (s_len, n, int(num_heads), float(p_attn), float(p_out), int(seed_attn), int(seed_out))
         ctx.param_leaves = _all_leaves(w_in, b_in, w_out, b_out)
+        ctx.norm_leaves = _all_leaves(gamma, beta)
         return y.view(s_len, n, d)
 
     @staticmethod
@@ -1599,7 +1629,6 @@ class _PreNormTemporalAttention(torch.autograd.Function):
                       d, st)
         else:
             dz = dy2
-        ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, d), dev)
         dw_out, db_out = _weight_grad(dz, dz.stride(0), o, d, m, d, d, dev, leaves=ctx.param_leaves)
         do = torch.empty(m, d, dtype=torch.float32, device=dev)
         _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, None, 0,
@@ -1612,10 +1641,7 @@ class _PreNormTemporalAttention(torch.autograd.Function):
         _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, None, 0,
                   _p(dxn), d, st)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(d, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_ln_bwd", _p(dxn), d, _p(x2), x2.stride(0), _p(stats), _p(gamma), _p(beta), 0, m, d, _p(dy2),
-                  dy2.stride(0), _p(dx), d, _p(dgamma), _p(dbeta), _p(ws), ws.numel(), st)
+        dgamma, dbeta = _ln_backward(dxn, x2, x2.stride(0), stats, gamma, beta, 0, m, d, dy2, dx, st, ctx.norm_leaves)
         return (dx.view(s_len, n, d), dgamma, dbeta, None, dw_in, db_in, dw_out, db_out, None, None, None, None, None)
 
 

@@ -323,11 +323,26 @@ size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N);
  * z and stats, computes dz [M,N], dgamma [N], dbeta [N] (N <= 128).  add (may be NULL, [M,N] with
  * row stride add_ld) is added to dz: the gradient that reaches the un-normalised tensor through the
  * residual connection around the block (x + block(norm(x)), models/local_encoder.py:151-153,266-267;
- * models/global_interactor.py:104-105), so that the two routes are summed without another pass. */
+ * models/global_interactor.py:104-105), so that the two routes are summed without another pass.
+ * With dgamma == dbeta == NULL the kernel's per-workgroup partial sums are left in `workspace`
+ * ([hivt_ln_bwd_partial_rows(M)][2][N] floats: the dgamma terms, then the dbeta terms of each workgroup) and
+ * no reduction is launched: the caller sums them later, e.g. all LayerNorms of a backward pass in one
+ * hivt_reduce_rows_group call (same summation order, same bits). */
 int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
                 const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
                 int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
                 size_t workspace_bytes, hivt_stream_t stream);
+
+/* Rows of partial sums hivt_ln_bwd leaves for M input rows (0 for M == 0). */
+size_t hivt_ln_bwd_partial_rows(int64_t M);
+
+/* count reductions over rows in shared launches (48 per launch): item i = items[8 i .. 8 i + 7] =
+ * (partial float* [R, pitch], R, pitch, C, out float*, split, out1 float* or 0, accumulate):
+ * out[c] (c < split) or out1[c - split] (c >= split) (+)= sum over r < R of partial[r * pitch + c], c < C, summed
+ * in a fixed order (16 row slices for R >= 64, 4 below; ascending inside a slice, slices in order): the
+ * parameter gradients of the LayerNorms (models/local_encoder.py:114-115, models/embedding.py:16-23) from the
+ * partial sums of hivt_ln_bwd, issued once per backward pass instead of once per LayerNorm. */
+int hivt_reduce_rows_group(const int64_t* items, int32_t count, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Temporal encoder attention core (next-row component: TemporalEncoder)

@@ -107,3 +107,50 @@ def test_step_with_deferred_weight_gradients_equals_the_plain_step(use_gan):
         assert torch.equal(a, b), k
     for k in logs_plain:
         assert torch.equal(logs_plain[k], logs_deferred[k]), k
+
+
+def test_grouped_row_sums_equal_the_single_layer_norm_backward_calls():
+    """hivt_ln_bwd leaving its partial sums + one hivt_reduce_rows_group for several LayerNorms == one
+    hivt_ln_bwd call each, bit for bit (same slices, same order); zero rows, accumulation and a split target."""
+    import ctypes
+    from hivt_gan_amd import _lib
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    cases, flat, keep = [], [], []
+    for m, n in ((5, 128), (300, 64), (4000, 128), (70_000, 128), (1, 16)):
+        x = torch.randn(m, n, device=dev)
+        dy = torch.randn(m, n, device=dev)
+        g, b = torch.randn(n, device=dev), torch.randn(n, device=dev)
+        y, stats = torch.empty_like(x), torch.empty(m, 2, device=dev)
+        _lib.call("hivt_ln_fwd", x.data_ptr(), n, g.data_ptr(), b.data_ptr(), 1e-5, m, n, y.data_ptr(), n,
+                  stats.data_ptr(), stream)
+        ws = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dtype=torch.uint8, device=dev)
+        dz0, dg0, db0 = torch.empty_like(x), torch.empty(n, device=dev), torch.empty(n, device=dev)
+        _lib.call("hivt_ln_bwd", dy.data_ptr(), n, x.data_ptr(), n, stats.data_ptr(), g.data_ptr(), b.data_ptr(), 0, m, n,
+                  None, 0, dz0.data_ptr(), n, dg0.data_ptr(), db0.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        rows = _lib.query("hivt_ln_bwd_partial_rows", m)
+        part = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", m, n) // 4, device=dev)
+        assert part.numel() >= rows * 2 * n
+        dz1, dg1, db1 = torch.empty_like(x), torch.full((n,), 7.0, device=dev), torch.full((n,), 7.0, device=dev)
+        _lib.call("hivt_ln_bwd", dy.data_ptr(), n, x.data_ptr(), n, stats.data_ptr(), g.data_ptr(), b.data_ptr(), 0, m, n,
+                  None, 0, dz1.data_ptr(), n, None, None, part.data_ptr(), part.numel() * 4, stream)
+        flat += [part.data_ptr(), rows, 2 * n, 2 * n, dg1.data_ptr(), n, db1.data_ptr(), 0]
+        keep.append(part)
+        cases.append((dz0, dg0, db0, dz1, dg1, db1))
+    # plain sums: accumulate into what the target holds, one target, no partial rows at all
+    p = torch.randn(100, 40, device=dev)
+    acc = torch.ones(40, device=dev)
+    flat += [p.data_ptr(), 100, 40, 40, acc.data_ptr(), 1 << 30, 0, 1]
+    none = torch.full((8,), 5.0, device=dev)
+    flat += [0, 0, 8, 8, none.data_ptr(), 1 << 30, 0, 0]
+    count = len(flat) // 8
+    _lib.call("hivt_reduce_rows_group", (ctypes.c_int64 * len(flat))(*flat), count, stream)
+    torch.cuda.synchronize()
+    for dz0, dg0, db0, dz1, dg1, db1 in cases:
+        assert torch.equal(dz0, dz1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.allclose(acc, 1.0 + p.sum(0), rtol=1e-5, atol=1e-5)
+    assert torch.all(none == 0)
+    with pytest.raises(_lib.HivtLibraryError):
+        _lib.call("hivt_reduce_rows_group", (ctypes.c_int64 * 8)(p.data_ptr(), 4, 2, 40, acc.data_ptr(), 50, 0, 0), 1,
+                  stream)  # a pitch below the column count
