@@ -16,6 +16,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBK = 32;
 constexpr int kThreads = 256;
@@ -133,6 +135,53 @@ struct Stage {
     }
   }
 
+  // Interior tiles (MASKED = false, VEC): a thread's piece r of every step lies at a fixed byte offset from the
+  // step's origin inside the operand, so the offsets are computed once (offsets()), the origin is a wave-uniform
+  // pointer that the caller moves from step to step with scalar arithmetic (origin() + step * step_bytes()),
+  // and a fetch is NVEC loads without any per-lane address work.  `live` false: the step lies past the end of
+  // the reduction range (the deep routes fetch ahead); the caller then passes the last step's origin, and the
+  // values take no part in the running column sums.
+  bool live = true;
+
+  __device__ static __forceinline__ void offsets(const Operand& op, int tid, unsigned (&off)[NVEC]) {
+#pragma unroll
+    for (int r = 0; r < NVEC; ++r) {
+      const int idx = tid + r * kThreads;
+      int row, red;
+      if (TRANS) {
+        row = idx / (kBK / 4);
+        red = (idx % (kBK / 4)) * 4;
+      } else if (PAIRED) {
+        const int pair = tid + (r >> 1) * kThreads;
+        red = 2 * (pair / (ROWS / 4)) + (r & 1);
+        row = (pair % (ROWS / 4)) * 4;
+      } else {
+        red = idx / (ROWS / 4);
+        row = (idx % (ROWS / 4)) * 4;
+      }
+      off[r] = (unsigned)(TRANS ? row * (int)op.ld + red : red * (int)op.ld + row) * 4u;
+    }
+  }
+
+  __device__ static __forceinline__ const char* origin(const Operand& op, int row0, int red0) {
+    return reinterpret_cast<const char*>(op.p + (TRANS ? (int64_t)row0 * op.ld + red0 : (int64_t)red0 * op.ld + row0));
+  }
+
+  __device__ static __forceinline__ int64_t step_bytes(const Operand& op) {
+    return (TRANS ? (int64_t)kBK : (int64_t)kBK * op.ld) * 4;
+  }
+
+  // every offset of a step fits 32 bits (and the int arithmetic of offsets())
+  __device__ static __forceinline__ bool offsets_fit(const Operand& op) {
+    return op.ld * (int64_t)(TRANS ? ROWS : kBK) < (1ll << 28);
+  }
+
+  __device__ __forceinline__ void fetch(const char* step_origin, const unsigned (&off)[NVEC], bool is_live) {
+    live = is_live;
+#pragma unroll
+    for (int r = 0; r < NVEC; ++r) v[r] = *reinterpret_cast<const float4*>(step_origin + off[r]);
+  }
+
   // One float4 of the staged step (r < NVEC) goes to LDS; store() sends all of them.
   __device__ __forceinline__ float4 masked(int r) const {
     if constexpr (!MASKED) return v[r];
@@ -156,32 +205,35 @@ struct Stage {
       if ((r & 1) == 0) return;  // leaves together with its odd neighbour
       const float4 lo = masked(r - 1), hi = masked(r);
       if (ACCUM) {
-        const float4 sl = MASKED ? lo : zero_invalid(r - 1), sh = MASKED ? hi : zero_invalid(r);
-        colsum.x += sl.x + sh.x;
-        colsum.y += sl.y + sh.y;
-        colsum.z += sl.z + sh.z;
-        colsum.w += sl.w + sh.w;
+        if (MASKED || live) {  // `live` is uniform over the wave
+          colsum.x += lo.x + hi.x;
+          colsum.y += lo.y + hi.y;
+          colsum.z += lo.z + hi.z;
+          colsum.w += lo.w + hi.w;
+        }
       }
-      const f32x4 fl = {lo.x, lo.y, lo.z, lo.w}, fh = {hi.x, hi.y, hi.z, hi.w};
-      const s16x4 bl = __builtin_bit_cast(s16x4, __builtin_convertvector(fl, bf16x4));
-      const s16x4 bh = __builtin_bit_cast(s16x4, __builtin_convertvector(fh, bf16x4));
+      // row i of the pair: (lo[i], hi[i]) are its two consecutive reduction indices, one packed conversion each
+      const float l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
       const int pair = tid + (r >> 1) * kThreads;
       const int red = 2 * (pair / (ROWS / 4));
       const int row = (pair % (ROWS / 4)) * 4;
       unsigned* image = reinterpret_cast<unsigned*>(lds);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        image[((row + i) * PITCH_H + red) / 2] = (unsigned)(unsigned short)bl[i] | ((unsigned)(unsigned short)bh[i] << 16);
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 two = {l4[i], h4[i]};
+        image[((row + i) * PITCH_H + red) / 2] = __builtin_bit_cast(unsigned, __builtin_convertvector(two, bf16x2));
+      }
       return;
     }
     const int idx = tid + r * kThreads;
     const float4 val = masked(r);
     if (ACCUM) {
-      const float4 sv = MASKED ? val : zero_invalid(r);
-      colsum.x += sv.x;
-      colsum.y += sv.y;
-      colsum.z += sv.z;
-      colsum.w += sv.w;
+      if (MASKED || live) {
+        colsum.x += val.x;
+        colsum.y += val.y;
+        colsum.z += val.z;
+        colsum.w += val.w;
+      }
     }
     if (BF16) {
       const f32x4 f = {val.x, val.y, val.z, val.w};
@@ -267,8 +319,9 @@ struct Core {
     // a tile in the interior of both operands whose reduction range is whole steps (whole rounds of the
     // register sets on the deep routes, which run the padded steps too) needs no validity masks
     constexpr int ROUND = kBK * (DEEP > 0 ? 2 * DEEP : 1);
-    const bool whole = row0 + BM <= a.rows && col0 + BN <= b.rows && red_end <= a.red && red_end <= b.red &&
-                       (red_end - red_begin) % ROUND == 0 && red_end > red_begin;
+    const bool whole = VEC && row0 + BM <= a.rows && col0 + BN <= b.rows && red_end <= a.red && red_end <= b.red &&
+                       (red_end - red_begin) % ROUND == 0 && red_end > red_begin && SA::offsets_fit(a) &&
+                       SB::offsets_fit(b);
     if (whole)
       accumulate_impl<false>(a, b, row0, col0, red_begin, red_end, lds, acc0, acc1, a_colsum);
     else
@@ -389,12 +442,35 @@ struct Core {
           pb.store_piece(lds + dst + A_FLOATS, tid, piece - SA::NVEC);
       };
     };
+    // MASKED = false: fixed per-thread offsets and wave-uniform step origins (Stage::fetch); the step that a
+    // fetch names is clamped to the last one, so fetching ahead of the range stays inside the operand
+    unsigned aoff[SA::NVEC], boff[SB::NVEC];
+    const char* a0 = nullptr;
+    const char* b0 = nullptr;
+    int64_t a_step = 0, b_step = 0;
+    if constexpr (!MASKED) {
+      SA::offsets(a, tid, aoff);
+      SB::offsets(b, tid, boff);
+      a0 = SA::origin(a, row0, red_begin);
+      b0 = SB::origin(b, col0, red_begin);
+      a_step = SA::step_bytes(a);
+      b_step = SB::step_bytes(b);
+    }
+    auto fetch = [&](SA& pa, SB& pb, int step) {
+      if constexpr (MASKED) {
+        pa.load(a, row0, red_begin + step * kBK, tid);
+        pb.load(b, col0, red_begin + step * kBK, tid);
+      } else {
+        const int t = step < steps ? step : steps - 1;
+        pa.fetch(a0 + (int64_t)t * a_step, aoff, step < steps);
+        pb.fetch(b0 + (int64_t)t * b_step, boff, step < steps);
+      }
+    };
     if constexpr (DEEP == 0) {
       SA sa;
       SB sb;
       if (steps > 0) {
-        sa.load(a, row0, red_begin, tid);
-        sb.load(b, col0, red_begin, tid);
+        fetch(sa, sb, 0);
         sa.store(lds, tid);
         sb.store(lds + A_FLOATS, tid);
       }
@@ -403,10 +479,7 @@ struct Core {
       for (int s = 0; s < steps; ++s) {
         const int cur = (s & 1) * BUF;
         const int nxt = BUF - cur;
-        if (s + 1 < steps) {
-          sa.load(a, row0, red_begin + (s + 1) * kBK, tid);
-          sb.load(b, col0, red_begin + (s + 1) * kBK, tid);
-        }
+        if (s + 1 < steps) fetch(sa, sb, s + 1);
         multiply(cur, nothing);
         if (s + 1 < steps) {
           sa.store(lds + nxt, tid);
@@ -424,10 +497,7 @@ struct Core {
       SA sa[D];
       SB sb[D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        sa[j].load(a, row0, red_begin + j * kBK, tid);
-        sb[j].load(b, col0, red_begin + j * kBK, tid);
-      }
+      for (int j = 0; j < D; ++j) fetch(sa[j], sb[j], j);
       sa[0].store(lds, tid);
       sb[0].store(lds + A_FLOATS, tid);
       __syncthreads();
@@ -437,8 +507,7 @@ struct Core {
         for (int j = 0; j < D; ++j) {
           // step s + j: multiply buffer j & 1; set j (its step is in LDS already) fetches step s + j + D; set
           // j + 1 (step s + j + 1) is published in the other buffer while the matrix unit is busy
-          sa[j].load(a, row0, red_begin + (s + j + D) * kBK, tid);
-          sb[j].load(b, col0, red_begin + (s + j + D) * kBK, tid);
+          fetch(sa[j], sb[j], s + j + D);
           multiply((j & 1) * BUF, publish(sa[(j + 1) % D], sb[(j + 1) % D], ((j + 1) & 1) * BUF));
           __syncthreads();
         }
