@@ -84,6 +84,24 @@ struct Stage {
   // stores per pair instead of eight 16-bit ones
   static constexpr bool PAIRED = BF16 && !TRANS;
   static_assert(!PAIRED || NVEC % 2 == 0, "paired staging needs an even number of pieces");
+  static_assert(!PAIRED || ROWS % 64 == 0, "paired staging covers 64-row segments");
+  // (the running column sums rely on a thread staging the same four rows in every piece)
+  static_assert(!(PAIRED && ACCUM) || ROWS == 64, "column sums of paired staging: one 64-row segment");
+
+  // bf16 image: the four 16-byte chunks of a row's 32 k trade places by the row's bits 3-4.  The matrix
+  // instruction's operand reads (one chunk per lane) do not care; the 32-bit stores of the paired staging do:
+  // sixteen lanes hold rows 4 apart, which an 80-byte row pitch maps to two banks -- with the exchange they
+  // spread over eight, and the four quarter-waves (four different words of the chunk) over all thirty-two.
+  __device__ static __forceinline__ int image_half(int row, int k) {
+    return row * PITCH_H + ((((k >> 3) ^ (row >> 3)) & 3) << 3) + (k & 7);
+  }
+
+  // paired staging: pair p of a step = rows 4 (p % 16) .. + 3 of 64-row segment p / 256, reduction indices
+  // 2 ((p / 16) % 16) and + 1: a quarter-wave reads 256 contiguous bytes and owns one reduction pair
+  __device__ static __forceinline__ void pair_place(int pair, int& row, int& red) {
+    row = (pair >> 8) * 64 + (pair & 15) * 4;
+    red = 2 * ((pair >> 4) & 15);
+  }
   float4 v[NVEC];
   unsigned ok;  // 4 validity bits per float4; applied when the values are written to LDS
   float4 colsum = {0.f, 0.f, 0.f, 0.f};  // ACCUM: running sum of everything this thread staged
@@ -100,9 +118,8 @@ struct Stage {
         row = idx / (kBK / 4);
         red = (idx % (kBK / 4)) * 4;
       } else if (PAIRED) {
-        const int pair = tid + (r >> 1) * kThreads;
-        red = 2 * (pair / (ROWS / 4)) + (r & 1);
-        row = (pair % (ROWS / 4)) * 4;
+        pair_place(tid + (r >> 1) * kThreads, row, red);
+        red += r & 1;
       } else {
         red = idx / (ROWS / 4);
         row = (idx % (ROWS / 4)) * 4;
@@ -152,9 +169,8 @@ struct Stage {
         row = idx / (kBK / 4);
         red = (idx % (kBK / 4)) * 4;
       } else if (PAIRED) {
-        const int pair = tid + (r >> 1) * kThreads;
-        red = 2 * (pair / (ROWS / 4)) + (r & 1);
-        row = (pair % (ROWS / 4)) * 4;
+        pair_place(tid + (r >> 1) * kThreads, row, red);
+        red += r & 1;
       } else {
         red = idx / (ROWS / 4);
         row = (idx % (ROWS / 4)) * 4;
@@ -214,14 +230,13 @@ struct Stage {
       }
       // row i of the pair: (lo[i], hi[i]) are its two consecutive reduction indices, one packed conversion each
       const float l4[4] = {lo.x, lo.y, lo.z, lo.w}, h4[4] = {hi.x, hi.y, hi.z, hi.w};
-      const int pair = tid + (r >> 1) * kThreads;
-      const int red = 2 * (pair / (ROWS / 4));
-      const int row = (pair % (ROWS / 4)) * 4;
+      int row, red;
+      pair_place(tid + (r >> 1) * kThreads, row, red);
       unsigned* image = reinterpret_cast<unsigned*>(lds);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x2 two = {l4[i], h4[i]};
-        image[((row + i) * PITCH_H + red) / 2] = __builtin_bit_cast(unsigned, __builtin_convertvector(two, bf16x2));
+        image[image_half(row + i, red) / 2] = __builtin_bit_cast(unsigned, __builtin_convertvector(two, bf16x2));
       }
       return;
     }
@@ -242,10 +257,10 @@ struct Stage {
       unsigned short* image = reinterpret_cast<unsigned short*>(lds);
       const int row = idx / (kBK / 4);
       const int red = (idx % (kBK / 4)) * 4;
-      *reinterpret_cast<bf16x4*>(image + row * PITCH_H + red) = h;
+      *reinterpret_cast<bf16x4*>(image + image_half(row, red)) = h;
       if constexpr (SPLIT3) {
         const f32x4 rest = f - __builtin_convertvector(h, f32x4);  // exact: hi shares f's leading bits
-        *reinterpret_cast<bf16x4*>(image + PLANE_H + row * PITCH_H + red) = __builtin_convertvector(rest, bf16x4);
+        *reinterpret_cast<bf16x4*>(image + PLANE_H + image_half(row, red)) = __builtin_convertvector(rest, bf16x4);
       }
     } else if (TRANS) {
       const int row = idx / (kBK / 4);
@@ -355,19 +370,22 @@ struct Core {
         // v_mfma_f32_32x32x16_bf16: lane (row lo, half hi) supplies k = 8*hi .. 8*hi + 7 of its row in each
         // group of 16 k; two groups cover the 32 k of a step, all operand reads (16 bytes each) go first
         const unsigned short* image = reinterpret_cast<const unsigned short*>(lds + cur);
-        const unsigned short* pa = image + (wr * 32 + lo) * SA::PITCH_H + 8 * hi;
-        const unsigned short* pb = image + 2 * A_FLOATS + (wc * 64 + lo) * SB::PITCH_H + 8 * hi;
+        // (rows lo and lo + 32 of a tile exchange their chunks the same way: bits 3-4 of the row agree)
+        const unsigned short* pa = image;
+        const unsigned short* pb = image + 2 * A_FLOATS;
         constexpr int G = kBK / 16;
         bf16x8 ah[G], b0h[G], b1h[G], al[G], b0l[G], b1l[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          ah[g] = *reinterpret_cast<const bf16x8*>(pa + 16 * g);
-          b0h[g] = *reinterpret_cast<const bf16x8*>(pb + 16 * g);
-          b1h[g] = *reinterpret_cast<const bf16x8*>(pb + 32 * SB::PITCH_H + 16 * g);
+          const int ka = SA::image_half(wr * 32 + lo, 16 * g + 8 * hi);
+          const int kb = SB::image_half(wc * 64 + lo, 16 * g + 8 * hi);
+          ah[g] = *reinterpret_cast<const bf16x8*>(pa + ka);
+          b0h[g] = *reinterpret_cast<const bf16x8*>(pb + kb);
+          b1h[g] = *reinterpret_cast<const bf16x8*>(pb + 32 * SB::PITCH_H + kb);
           if constexpr (SPLIT3) {
-            al[g] = *reinterpret_cast<const bf16x8*>(pa + SA::PLANE_H + 16 * g);
-            b0l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 16 * g);
-            b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 32 * SB::PITCH_H + 16 * g);
+            al[g] = *reinterpret_cast<const bf16x8*>(pa + SA::PLANE_H + ka);
+            b0l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + kb);
+            b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 32 * SB::PITCH_H + kb);
           }
         }
         // HIVT_FENCE: nothing moves across -- the conversions of the operand set that is being published
