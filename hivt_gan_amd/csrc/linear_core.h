@@ -88,12 +88,16 @@ struct Stage {
   // (the running column sums rely on a thread staging the same four rows in every piece)
   static_assert(!(PAIRED && ACCUM) || ROWS == 64, "column sums of paired staging: one 64-row segment");
 
-  // bf16 image: the four 16-byte chunks of a row's 32 k trade places by the row's bits 3-4.  The matrix
-  // instruction's operand reads (one chunk per lane) do not care; the 32-bit stores of the paired staging do:
-  // sixteen lanes hold rows 4 apart, which an 80-byte row pitch maps to two banks -- with the exchange they
-  // spread over eight, and the four quarter-waves (four different words of the chunk) over all thirty-two.
+  // bf16 image: the four 16-byte chunks of a row's 32 k trade places by the row's bits 4-5.  Sixteen
+  // consecutive rows (an aligned group: one exchange for all of them) still start on sixteen distinct groups
+  // of four of the 64 banks, which is what the operand reads (one chunk per lane) need; the 32-bit stores of
+  // the paired staging gain: sixteen lanes hold rows 4 apart, which an 80-byte row pitch maps to four banks --
+  // with the exchange they spread over sixteen, and the four quarter-waves (four different words of the
+  // chunk) over all sixty-four.
+  // (Only images written by the paired staging exchange chunks; the others keep plain rows.)
   __device__ static __forceinline__ int image_half(int row, int k) {
-    return row * PITCH_H + ((((k >> 3) ^ (row >> 3)) & 3) << 3) + (k & 7);
+    if constexpr (!PAIRED) return row * PITCH_H + k;
+    return row * PITCH_H + ((((k >> 3) ^ (row >> 4)) & 3) << 3) + (k & 7);
   }
 
   // paired staging: pair p of a step = rows 4 (p % 16) .. + 3 of 64-row segment p / 256, reduction indices
@@ -370,7 +374,7 @@ struct Core {
         // v_mfma_f32_32x32x16_bf16: lane (row lo, half hi) supplies k = 8*hi .. 8*hi + 7 of its row in each
         // group of 16 k; two groups cover the 32 k of a step, all operand reads (16 bytes each) go first
         const unsigned short* image = reinterpret_cast<const unsigned short*>(lds + cur);
-        // (rows lo and lo + 32 of a tile exchange their chunks the same way: bits 3-4 of the row agree)
+        // (rows lo and lo + 64 of a tile exchange their chunks the same way; lo + 32 is looked up on its own)
         const unsigned short* pa = image;
         const unsigned short* pb = image + 2 * A_FLOATS;
         constexpr int G = kBK / 16;
@@ -381,11 +385,12 @@ struct Core {
           const int kb = SB::image_half(wc * 64 + lo, 16 * g + 8 * hi);
           ah[g] = *reinterpret_cast<const bf16x8*>(pa + ka);
           b0h[g] = *reinterpret_cast<const bf16x8*>(pb + kb);
-          b1h[g] = *reinterpret_cast<const bf16x8*>(pb + 32 * SB::PITCH_H + kb);
+          const int kb1 = SB::image_half(wc * 64 + 32 + lo, 16 * g + 8 * hi);
+          b1h[g] = *reinterpret_cast<const bf16x8*>(pb + kb1);
           if constexpr (SPLIT3) {
             al[g] = *reinterpret_cast<const bf16x8*>(pa + SA::PLANE_H + ka);
             b0l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + kb);
-            b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + 32 * SB::PITCH_H + kb);
+            b1l[g] = *reinterpret_cast<const bf16x8*>(pb + SB::PLANE_H + kb1);
           }
         }
         // HIVT_FENCE: nothing moves across -- the conversions of the operand set that is being published
