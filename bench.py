@@ -280,7 +280,8 @@ def main():
             c = [int(v) for v in caps.tolist()]
             spec = hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:]))
             trainer.edge_capacity = spec.edge_capacity
-        padded = [hv.pad_batch(b, spec) for b, _ in pool]
+        from hivt_gan_amd.graph import pack_inputs
+        padded = [pack_inputs(hv.pad_batch(b, spec)) for b, _ in pool]  # one buffer per batch: one copy per step
         try:
             graphed = GraphedStep(trainer, spec, padded[0], critic_streams=bool(tuned.get("critic_streams", False)))
         except Exception as exc:  # noqa: BLE001 -- the eager step is always available

@@ -33,6 +33,29 @@ _INPUT_KEYS = ("x", "positions", "y", "padding_mask", "bos_mask", "rotate_angles
                "turn_directions", "traffic_controls", "edge_index", "lane_actor_index", "lane_actor_vectors", "scene_range")
 
 
+def pack_inputs(batch: TemporalData) -> TemporalData:
+    """The tensors of a padded GPU batch that a step reads, re-laid as views of ONE byte buffer (each on a 256-byte
+    boundary).  A batch packed this way is handed to a recording with the same layout in a single device copy
+    instead of one per tensor.  Returns a new batch; the given one is left alone."""
+    keys = [k for k in _INPUT_KEYS if k in batch]
+    layout, total = [], 0
+    for k in keys:
+        t = batch[k]
+        layout.append((k, total, tuple(t.shape), t.dtype))
+        total += -(-t.numel() * t.element_size() // 256) * 256
+    dev = batch[keys[0]].device
+    arena = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
+    out = TemporalData(**{k: batch[k] for k in batch.keys() if k not in ("edge_plan", "_arena", "_arena_layout")})
+    for k, off, shape, dtype in layout:
+        n = batch[k].numel() * batch[k].element_size()
+        view = arena[off:off + n].view(dtype).view(shape)
+        view.copy_(batch[k])
+        out[k] = view
+    out["_arena"] = arena
+    out["_arena_layout"] = tuple(layout)
+    return out
+
+
 _HIP_NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
                    7: "event_record"}
 
@@ -82,9 +105,10 @@ class GraphedStep:
     """``trainer.step`` on fixed-shape batches as one graph launch (single process) or as a few graph
     segments with the gradient all-reduces between them (data parallel).
 
-    ``example`` is a batch already padded to ``spec`` and resident on the GPU; its tensors become the
-    static inputs of the recording.  ``run(batch)`` copies another padded batch into them (a dozen
-    device-to-device copies) and replays; ``run()`` replays on whatever the static inputs hold."""
+    ``example`` is a batch already padded to ``spec`` and resident on the GPU; copies of its tensors become
+    the static inputs of the recording.  ``run(batch)`` copies another padded batch into them (one
+    device-to-device copy for a batch prepared with ``pack_inputs``, a dozen otherwise) and replays; ``run()``
+    replays on whatever the static inputs hold."""
 
     def __init__(self, trainer, spec: BatchSpec, example: TemporalData, warmup: int = 3,
                  critic_streams: bool = False) -> None:
@@ -92,8 +116,11 @@ class GraphedStep:
             raise RuntimeError("a recorded step needs the read-back-free mode (GanTrainer(edge_capacity=...))")
         self.trainer = trainer
         self.spec = spec
-        self.static = TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
-                                      for k in example.keys() if k != "edge_plan"})
+        # the static inputs live in one byte buffer (pack_inputs), so that a batch laid out the same way arrives
+        # in one copy
+        self.static = pack_inputs(TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
+                                                  for k in example.keys()
+                                                  if k not in ("edge_plan", "_arena", "_arena_layout")}))
         self._y = self.static["y"]
         dev = self._y.device
         self.device = dev
@@ -195,7 +222,11 @@ class GraphedStep:
                     for g in opt.param_groups]
 
     def load(self, batch: TemporalData) -> None:
-        """Copies a batch padded to the same ``BatchSpec`` into the static inputs."""
+        """Copies a batch padded to the same ``BatchSpec`` into the static inputs: one copy for a batch that
+        ``pack_inputs`` laid out like them, one copy per tensor otherwise."""
+        if batch.get("_arena_layout") is not None and batch["_arena_layout"] == self.static["_arena_layout"]:
+            self.static["_arena"].copy_(batch["_arena"], non_blocking=True)
+            return
         for k in _INPUT_KEYS:
             if k not in self.static:
                 continue
@@ -223,5 +254,5 @@ class GraphedStep:
 
 
 def padded_pool(batches, spec: BatchSpec):
-    """Every batch of ``batches`` (GPU) padded to ``spec``."""
-    return [pad_batch(b, spec) for b in batches]
+    """Every batch of ``batches`` (GPU) padded to ``spec`` and packed for one-copy loading."""
+    return [pack_inputs(pad_batch(b, spec)) for b in batches]

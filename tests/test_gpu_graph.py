@@ -50,13 +50,19 @@ def test_replayed_steps_equal_eager_steps():
     trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
     step = GraphedStep(trainer, spec, padded[0], warmup=3)
     assert step.nodes.get("memset", 0) == 0 and step.nodes.get("kernel", 0) > 100, step.nodes
+    # batches laid out in one buffer arrive in a single copy, plain ones tensor by tensor: same steps either way
+    from hivt_gan_amd.graph import pack_inputs
+    packed = [pack_inputs(b) if i % 2 == 0 else b for i, b in enumerate(padded)]
+    assert packed[0]["_arena_layout"] == step.static["_arena_layout"]
     for i in order:
-        logs = step.run(padded[i])
+        logs = step.run(packed[i])
     torch.cuda.synchronize()
     assert float(logs["skipped"]) == 0.0
     for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
         assert torch.equal(a, b), f"{k} differs between replayed and eager steps"
     assert trainer.overflowed_steps() == 0
+    for k in ("x", "padding_mask", "edge_index", "lane_actor_vectors"):
+        assert torch.equal(step.static[k], padded[order[-1]][k]), k
 
 
 def test_tripped_guard_in_a_replay_leaves_the_model_untouched():
