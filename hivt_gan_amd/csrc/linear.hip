@@ -44,14 +44,16 @@ template <int BM, int BN, int EPI, bool VEC, int DEEP = 0, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_fwd_kernel(const FwdArgs a) {
   using C = Core<BM, BN, true, true, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y > 1) xcd_walk(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, bx, by);  // column tiles share x rows
+  const int row0 = bx * BM, col0 = by * BN;
   Operand xa = a.x, wa = a.w;
   f32x16 acc0, acc1;
   const float2 bias2 = C::bias_pair(a.t, col0, a.N);
   HIVT_STAMP(0);
 #ifdef HIVT_PROBE
   if (threadIdx.x == 0 && d_probe != nullptr) {  // where the block ran: HW_ID and XCC_ID registers
-    long long* slot = d_probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    long long* slot = d_probe + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;  // by dispatch id
     slot[4] = __builtin_amdgcn_s_getreg(4 | (31 << 11));
     slot[5] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
   }
@@ -157,7 +159,9 @@ template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
   using C = Core<BM, BN, true, false, VEC, false, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (gridDim.y > 1) xcd_walk(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, bx, by);  // column tiles share dy rows
+  const int row0 = bx * BM, col0 = by * BN;
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
   Tail t{};
@@ -237,7 +241,11 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   __shared__ float bsum[kThreads / (BM / 4)][BM];
-  wgrad_tile<BM, BN, VEC, DEEP, PREC>(a, blockIdx.x, blockIdx.y, blockIdx.z, lds, bsum, false);
+  // the tiles of a row chunk on one XCD (see the grouped kernel)
+  const int tiles = gridDim.x * gridDim.y;
+  int chunk, tile;
+  xcd_walk(blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x, gridDim.z, tiles, chunk, tile);
+  wgrad_tile<BM, BN, VEC, DEEP, PREC>(a, tile % gridDim.x, tile / gridDim.x, chunk, lds, bsum, false);
 }
 
 // Several small weight gradients in one launch: workgroup b belongs to the term whose block range holds b
@@ -262,8 +270,15 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_group_kernel(const Wgra
   const WgradArgs& a = g.item[i];
   const int local = (int)blockIdx.x - g.first_block[i];
   const int tiles_n = (a.N + BM - 1) / BM, tiles_k = (a.K + BN - 1) / BN;
-  wgrad_tile<BM, BN, true, true, PREC>(a, local % tiles_n, (local / tiles_n) % tiles_k, local / (tiles_n * tiles_k), lds,
-                                      bsum, g.zero_bias[i] != 0);
+  // The tiles of one row chunk read the same rows of both operands.  Workgroups are dealt round-robin over
+  // the eight XCDs (each with an L2 of its own), so eight chunks are walked at a time, one per XCD: the tiles
+  // of a chunk get workgroup ids that agree modulo 8 and find the chunk's rows in their L2 instead of fetching
+  // them once per tile.  (Placement is an observation, not a contract: only speed depends on it.)
+  const int tiles = tiles_n * tiles_k;
+  const int chunks = (a.M + a.chunk_rows - 1) / a.chunk_rows;
+  int tile, chunk;
+  xcd_walk(local, chunks, tiles, chunk, tile);
+  wgrad_tile<BM, BN, true, true, PREC>(a, tile % tiles_n, tile / tiles_n, chunk, lds, bsum, g.zero_bias[i] != 0);
 }
 
 // The reductions over the chunks of a group, in the association of reduce_rows_kernel<64, 4>: per term four

@@ -44,6 +44,23 @@ __device__ long long* d_probe = nullptr;
 #define HIVT_STAMP(i) do { } while (0)
 #endif
 
+// Workgroups that read the same rows of an operand (the column tiles of one row tile; the tiles of one row chunk
+// of a weight gradient) should share an L2.  Workgroups are dealt round-robin over the eight XCDs in the order of
+// their linear id, so the `inner` siblings of eight consecutive `outer` units are walked together, one unit per
+// XCD: sibling s of unit u gets a linear id that agrees modulo 8 with its other siblings.  Placement is an
+// observation, not a contract -- only speed depends on it.  linear: the workgroup's id in dispatch order.
+__device__ __forceinline__ void xcd_walk(int linear, int outer_count, int inner_count, int& outer, int& inner) {
+  const int grouped = outer_count / 8 * 8 * inner_count;
+  if (linear < grouped) {
+    const int rem = linear % (8 * inner_count);
+    outer = linear / (8 * inner_count) * 8 + rem % 8;
+    inner = rem / 8;
+  } else {
+    outer = outer_count / 8 * 8 + (linear - grouped) / inner_count;
+    inner = (linear - grouped) % inner_count;
+  }
+}
+
 // Operand descriptor: logical matrix Op[row][red] (row = output index, red = reduction index).
 // TRANS = true : memory is [row][red] (contiguous along the reduction)  -> transposing stage
 // TRANS = false: memory is [red][row] (contiguous along the output row) -> straight copy
