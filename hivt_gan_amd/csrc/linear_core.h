@@ -92,7 +92,9 @@ struct Stage {
   static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
   static_assert(!SPLIT3 || TRANS, "split operands are built for [row][k] memory images only (the forward product)");
   static constexpr int PITCH = TRANS ? ROWS + 1 : ROWS + 4;
-  static constexpr int PITCH_H = kBK + 8;  // halves per row of the bf16 image
+  // halves per row of the bf16 image: 80-byte rows for images written by the paired staging, bare 64-byte rows
+  // (chunks exchanged by the row's bits 2-3, see image_half) for the others
+  static constexpr int PITCH_H = (BF16 && !TRANS) ? kBK + 8 : kBK;
   static constexpr int PLANE_H = ROWS * PITCH_H;  // halves of one image
   static constexpr int FLOATS = BF16 ? (SPLIT3 ? 2 : 1) * PLANE_H / 2 : kBK * PITCH;  // LDS floats of one staged step
   static constexpr int NVEC = ROWS * kBK / 4 / kThreads;  // float4 per thread per step
@@ -111,9 +113,13 @@ struct Stage {
   // the paired staging gain: sixteen lanes hold rows 4 apart, which an 80-byte row pitch maps to four banks --
   // with the exchange they spread over sixteen, and the four quarter-waves (four different words of the
   // chunk) over all sixty-four.
-  // (Only images written by the paired staging exchange chunks; the others keep plain rows.)
+  // Images of [row][k] operands (not written by the paired staging) have rows of exactly 64 bytes: a quarter of
+  // the image's LDS goes, and with it a workgroup per compute unit more fits.  Their chunks trade places by the
+  // row's bits 2-3: the sixteen lanes of a ds_read_b128 group read sixteen rows whose (row & 3, row >> 2 & 3)
+  // pairs are all different, i.e. sixteen distinct groups of four banks; the 8-byte stores of a row fill its 64
+  // bytes whatever the order.
   __device__ static __forceinline__ int image_half(int row, int k) {
-    if constexpr (!PAIRED) return row * PITCH_H + k;
+    if constexpr (!PAIRED) return row * PITCH_H + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
     return row * PITCH_H + ((((k >> 3) ^ (row >> 4)) & 3) << 3) + (k & 7);
   }
 
