@@ -55,12 +55,16 @@ SIGNATURES = {
                                      c_int64, _P, c_int64, _P]),
     "hivt_linear_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_linear_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_linear_wgrad_half": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, c_size_t, c_int32,
+                                       _P]),
     "hivt_linear_wgrad_group_workspace_bytes": (c_size_t, [_P, c_int32]),
     "hivt_linear_wgrad_group": (c_int, [_P, c_int32, _P, c_size_t, _P]),
     "hivt_ln_fwd": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int32, _P, c_int64, _P, _P]),
     "hivt_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_ln_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_int64, c_int32, _P, c_int64, _P, c_int64,
                             _P, _P, _P, c_size_t, _P]),
+    "hivt_linear_bwd_data_half": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_float, _P,
+                                          c_int64, _P, c_int64, c_int32, _P]),
     "hivt_ln_bwd_partial_rows": (c_size_t, [c_int64]),
     "hivt_reduce_rows_group": (c_int, [_P, c_int32, _P]),
     "hivt_temporal_attn_fwd": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P]),

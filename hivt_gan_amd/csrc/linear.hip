@@ -155,11 +155,13 @@ struct BwdDataArgs {
   float mask_scale, mask_neg_scale;
   const float* add;   // optional [M,K], exclusive with mask: dx += add
   int64_t add_ld;
+  int32_t dx_half;    // dx is stored as bfloat16
 };
 
-template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32>
+// HY: dy holds bfloat16 values in memory
+template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32, bool HY = false>
 __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdDataArgs a) {
-  using C = Core<BM, BN, true, false, VEC, false, DEEP, PREC>;
+  using C = Core<BM, BN, true, false, VEC, false, DEEP, PREC, HY>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   int bx = blockIdx.x, by = blockIdx.y;
   if (gridDim.y > 1) xcd_walk(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x, gridDim.y, bx, by);  // column tiles share dy rows
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
     t.residual = a.add;
     t.res_ld = a.add_ld;
   }
+  t.out_half = a.dx_half != 0;
   C::template store_direct<false>(acc0, acc1, row0, col0, a.M, a.K, a.dx, a.dx_ld, t, make_float2(0.0f, 0.0f));
 }
 
@@ -189,15 +192,16 @@ struct WgradArgs {
   float* bias_partial;  // start of chunk 0's bias sums (each chunk: N*K weight sums, then N bias sums) or null
   int64_t pitch;        // floats per chunk: N*K (+ N with a bias)
   int32_t N, K, M, chunk_rows;
+  int32_t dy_half;      // dy is bfloat16 in memory (its leading dimension counts bfloat16 elements)
 };
 
 // One workgroup's share: the [BM x BN] tile (tile_n, tile_k) of the partial sums of row chunk `chunk`.
 // zero_bias: the chunk's bias slots are cleared instead of filled (a term without a bias gradient that shares
 // its partial buffer with one that has it).
-template <int BM, int BN, bool VEC, int DEEP, int PREC>
+template <int BM, int BN, bool VEC, int DEEP, int PREC, bool HY = false>
 __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int tile_n, int tile_k, int chunk, float* lds,
                                            float (*bsum)[BM], bool zero_bias) {
-  using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
+  using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC, HY>;
   const int row0 = tile_n * BM, col0 = tile_k * BN;
   const int m_begin = chunk * a.chunk_rows;
   const int m_end = min(a.M, m_begin + a.chunk_rows);
@@ -238,7 +242,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int tile_n, int t
   }
 }
 
-template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32>
+template <int BM, int BN, bool VEC, int DEEP = 0, int PREC = PREC_F32, bool HY = false>
 __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs a) {
   using C = Core<BM, BN, false, false, VEC, true, DEEP, PREC>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_kernel(const WgradArgs 
   const int tiles = gridDim.x * gridDim.y;
   int chunk, tile;
   xcd_walk(blockIdx.x + (blockIdx.y + blockIdx.z * gridDim.y) * gridDim.x, gridDim.z, tiles, chunk, tile);
-  wgrad_tile<BM, BN, VEC, DEEP, PREC>(a, tile % gridDim.x, tile / gridDim.x, chunk, lds, bsum, false);
+  wgrad_tile<BM, BN, VEC, DEEP, PREC, HY>(a, tile % gridDim.x, tile / gridDim.x, chunk, lds, bsum, false);
 }
 
 // Several small weight gradients in one launch: workgroup b belongs to the term whose block range holds b
@@ -280,7 +284,11 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_group_kernel(const Wgra
   const int chunks = (a.M + a.chunk_rows - 1) / a.chunk_rows;
   int tile, chunk;
   xcd_walk(local, chunks, tiles, chunk, tile);
-  wgrad_tile<BM, BN, true, true, PREC>(a, tile % tiles_n, tile / tiles_n, chunk, lds, bsum, g.zero_bias[i] != 0);
+  if (PREC == PREC_BF16 && a.dy_half)
+    wgrad_tile<BM, BN, true, true, PREC, PREC == PREC_BF16>(a, tile % tiles_n, tile / tiles_n, chunk, lds, bsum,
+                                                          g.zero_bias[i] != 0);
+  else
+    wgrad_tile<BM, BN, true, true, PREC>(a, tile % tiles_n, tile / tiles_n, chunk, lds, bsum, g.zero_bias[i] != 0);
 }
 
 // The reductions over the chunks of a group, in the association of reduce_rows_kernel<64, 4>: per term four
@@ -823,21 +831,42 @@ extern "C" int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int
 static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
                                 int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
                                 float mask_neg_scale, const float* add, int64_t add_ld, float* dx, int64_t dx_ld,
-                                hivt_stream_t stream) {
+                                hivt_stream_t stream, int half_flags = 0) {
   const char* what = "hivt_linear_bwd_data";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   if (M == 0) return HIVT_OK;
   HIVT_REQUIRE(dy && w && dx, HIVT_ERR_ARG, "%s: null pointer", what);
+  const bool dy_half = (half_flags & HIVT_HALF_DY) != 0, dx_half = (half_flags & HIVT_HALF_DX) != 0;
   BwdDataArgs a{};
-  a.dy = make_operand(dy, dy_ld, (int32_t)M, N, true);
+  a.dy = make_operand(dy, dy_ld, (int32_t)M, N, true, dy_half);
   a.w = make_operand(w, w_ld, K, N, false);  // W[n][k]: reduction index n is the row of the memory image
-  a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K;
+  a.dx = dx; a.dx_ld = dx_ld; a.M = (int32_t)M; a.K = K; a.dx_half = dx_half ? 1 : 0;
   HIVT_REQUIRE(mask == nullptr || add == nullptr, HIVT_ERR_UNSUPPORTED, "%s: mask and add are exclusive", what);
   a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale; a.mask_neg_scale = mask_neg_scale;
   a.add = add; a.add_ld = add_ld;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
   const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_DGRAD) != 0;
+  // bfloat16 gradients exist only between products that round their operands to bfloat16 anyway
+  HIVT_REQUIRE(half_flags == 0 || (bf16 && vec), HIVT_ERR_UNSUPPORTED,
+               "%s: bfloat16 dy / dx need the bf16 data-gradient mode and 8-byte aligned rows", what);
+  if (dy_half) {
+    if (K <= 64) {
+      dim3 grid((unsigned)((M + 127) / 128), 1);
+      if (grid.x <= kSmallGrid)
+        hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, true, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+      else
+        hipLaunchKernelGGL((linear_bwd_data_kernel<128, 64, true, false, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+    } else {
+      dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 127) / 128));
+      if (grid.x * grid.y <= kSmallGrid)
+        hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, true, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+      else
+        hipLaunchKernelGGL((linear_bwd_data_kernel<64, 128, true, false, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+    }
+    HIVT_CHECK_LAUNCH(what);
+    return HIVT_OK;
+  }
   if (K <= 64) {
     dim3 grid((unsigned)((M + 127) / 128), 1);
     if (vec && bf16 && grid.x <= kSmallGrid)
@@ -894,6 +923,14 @@ int linear_bwd_data_gated(const float* dy, int64_t dy_ld, const float* w, int64_
 
 }  // namespace hivt
 
+extern "C" int hivt_linear_bwd_data_half(const void* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M,
+                                         int32_t N, int32_t K, const float* mask, int64_t mask_ld, float mask_scale,
+                                         const float* add, int64_t add_ld, void* dx, int64_t dx_ld, int32_t half_flags,
+                                         hivt_stream_t stream) {
+  return linear_bwd_data_impl(reinterpret_cast<const float*>(dy), dy_ld, w, w_ld, M, N, K, mask, mask_ld, mask_scale, 0.0f,
+                              add, add_ld, reinterpret_cast<float*>(dx), dx_ld, stream, half_flags);
+}
+
 extern "C" size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   const int tiles = ((N + 63) / 64) * ((K + 127) / 128);
   const int chunks = pick_chunks(M, tiles);
@@ -902,7 +939,7 @@ extern "C" size_t hivt_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_
 
 static int linear_wgrad_impl(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
                              int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                             hivt_stream_t stream, bool accumulate) {
+                             hivt_stream_t stream, bool accumulate, bool dy_half = false) {
   const char* what = "hivt_linear_wgrad";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(dw != nullptr, HIVT_ERR_ARG, "%s: dw is null", what);
@@ -922,15 +959,22 @@ static int linear_wgrad_impl(const float* dy, int64_t dy_ld, const float* x, int
   const int chunk_rows = (int)(((M + chunks - 1) / chunks + kBK - 1) / kBK * kBK);
   const int real_chunks = (int)((M + chunk_rows - 1) / chunk_rows);
   WgradArgs a{};
-  a.dy = make_operand(dy, dy_ld, N, (int32_t)M, false);
+  a.dy = make_operand(dy, dy_ld, N, (int32_t)M, false, dy_half);
   a.x = make_operand(x, x_ld, K, (int32_t)M, false);
+  a.dy_half = dy_half ? 1 : 0;
   a.partial = reinterpret_cast<float*>(workspace);
   a.pitch = (int64_t)N * K + (dbias ? N : 0);
   a.bias_partial = dbias ? a.partial + (size_t)N * K : nullptr;
   a.N = N; a.K = K; a.M = (int32_t)M; a.chunk_rows = chunk_rows;
   dim3 grid((unsigned)tiles_n, (unsigned)tiles_k, (unsigned)real_chunks);
   const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_WGRAD) != 0;
-  if (a.dy.vec_ok && a.x.vec_ok && bf16 && grid.x * grid.y * grid.z <= kSmallGrid)
+  HIVT_REQUIRE(!dy_half || (bf16 && a.dy.vec_ok && a.x.vec_ok), HIVT_ERR_ARG,
+               "%s: a bfloat16 dy needs the bf16 weight-gradient mode and operands that allow wide loads", what);
+  if (dy_half && grid.x * grid.y * grid.z <= kSmallGrid)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+  else if (dy_half)
+    hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, false, PREC_BF16, true>), grid, dim3(kThreads), 0, s, a);
+  else if (a.dy.vec_ok && a.x.vec_ok && bf16 && grid.x * grid.y * grid.z <= kSmallGrid)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, true, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
   else if (a.dy.vec_ok && a.x.vec_ok && bf16)
     hipLaunchKernelGGL((linear_wgrad_kernel<64, 128, true, false, PREC_BF16>), grid, dim3(kThreads), 0, s, a);
@@ -954,6 +998,14 @@ extern "C" int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x,
   return linear_wgrad_impl(dy, dy_ld, x, x_ld, M, N, K, dw, dbias, workspace, workspace_bytes, stream, false);
 }
 
+extern "C" int hivt_linear_wgrad_half(const void* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                                      int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                                      int32_t half_flags, hivt_stream_t stream) {
+  HIVT_REQUIRE((half_flags & ~HIVT_HALF_DY) == 0, HIVT_ERR_ARG, "hivt_linear_wgrad_half: unknown flag bits");
+  return linear_wgrad_impl(reinterpret_cast<const float*>(dy), dy_ld, x, x_ld, M, N, K, dw, dbias, workspace,
+                           workspace_bytes, stream, false, (half_flags & HIVT_HALF_DY) != 0);
+}
+
 namespace hivt {
 int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
                             int32_t K, float* dw, void* workspace, size_t workspace_bytes, hivt_stream_t stream) {
@@ -964,7 +1016,8 @@ int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int6
 // ---------------------------------------------------------------------------------------------
 // Several weight gradients per call.  items: count x 10 int64 -- dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none),
 // flags (bit 0: add to what dw / dbias hold; bit 1: this term joins the item before it: same dw, its sum is
-// added to that item's, no bias term of its own).  Terms share launches, sixteen per launch, long chunks
+// added to that item's, no bias term of its own; bit 2: dy is bfloat16 in memory, dy_ld in bfloat16 elements,
+// bf16 weight-gradient mode only).  Terms share launches, sixteen per launch, long chunks
 // first.  A term that hivt_linear_wgrad would cut into fewer than 64 row chunks gets the same chunks and the
 // same order of sums here (bit-identical results); a longer one is summed in chunks of about 2048 rows (equal
 // to rounding).  Terms whose operands do not allow 16-byte loads go through the single-product path one by one.
@@ -973,7 +1026,7 @@ namespace {
 
 struct GroupItem {
   const float* dy; int64_t dy_ld; const float* x; int64_t x_ld; int64_t M; int32_t N, K; float* dw; float* dbias;
-  bool accumulate, joins;
+  bool accumulate, joins, dy_half;
   int chunks, chunk_rows, tiles;  // of the single-product path
   bool groupable;
   size_t ws_floats;               // its share of the workspace
@@ -982,6 +1035,7 @@ struct GroupItem {
 int parse_group(const char* what, const int64_t* items, int32_t count, std::vector<GroupItem>& out) {
   HIVT_REQUIRE(count >= 0 && (count == 0 || items != nullptr), HIVT_ERR_ARG, "%s: bad item table", what);
   out.resize((size_t)count);
+  const bool bf16_wgrad = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_WGRAD) != 0;
   for (int32_t i = 0; i < count; ++i) {
     const int64_t* t = items + (size_t)i * 10;
     GroupItem& g = out[(size_t)i];
@@ -989,7 +1043,7 @@ int parse_group(const char* what, const int64_t* items, int32_t count, std::vect
     g.x = reinterpret_cast<const float*>((uintptr_t)t[2]); g.x_ld = t[3];
     g.M = t[4]; g.N = (int32_t)t[5]; g.K = (int32_t)t[6];
     g.dw = reinterpret_cast<float*>((uintptr_t)t[7]); g.dbias = reinterpret_cast<float*>((uintptr_t)t[8]);
-    g.accumulate = (t[9] & 1) != 0; g.joins = (t[9] & 2) != 0;
+    g.accumulate = (t[9] & 1) != 0; g.joins = (t[9] & 2) != 0; g.dy_half = (t[9] & 4) != 0;
     HIVT_REQUIRE(g.M >= 0 && g.M < ((int64_t)1 << 31) && t[5] > 0 && t[6] > 0 && t[5] < ((int64_t)1 << 24) &&
                  t[6] < ((int64_t)1 << 24), HIVT_ERR_ARG, "%s: item %d: bad sizes", what, (int)i);
     HIVT_REQUIRE(g.dw != nullptr, HIVT_ERR_ARG, "%s: item %d: dw is null", what, (int)i);
@@ -1015,9 +1069,12 @@ int parse_group(const char* what, const int64_t* items, int32_t count, std::vect
         g.chunks = (int)((g.M + g.chunk_rows - 1) / g.chunk_rows);
       }
     }
-    const Operand a = make_operand(g.dy, g.dy_ld, g.N, (int32_t)g.M, false);
+    const Operand a = make_operand(g.dy, g.dy_ld, g.N, (int32_t)g.M, false, g.dy_half);
     const Operand b = make_operand(g.x, g.x_ld, g.K, (int32_t)g.M, false);
     g.groupable = g.M > 0 && a.vec_ok && b.vec_ok;
+    HIVT_REQUIRE(!g.dy_half || g.M == 0 || (g.groupable && bf16_wgrad), HIVT_ERR_ARG,
+                 "%s: item %d: a bfloat16 dy needs the bf16 weight-gradient mode and operands that allow wide loads",
+                 what, (int)i);
   }
   // an entry (an item and the one that joins it) goes through the grouped kernels only as a whole
   for (int32_t i = 0; i < count; ++i)
@@ -1058,7 +1115,7 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
     const GroupItem& it = g[(size_t)i];
     if (it.groupable) continue;
     const int rc = linear_wgrad_impl(it.dy, it.dy_ld, it.x, it.x_ld, it.M, it.N, it.K, it.dw, it.dbias, region[(size_t)i],
-                                     it.ws_floats * sizeof(float), stream, it.accumulate || it.joins);
+                                     it.ws_floats * sizeof(float), stream, it.accumulate || it.joins, it.dy_half);
     if (rc != HIVT_OK) return rc;
   }
   // grouped: the products, sixteen terms per launch ...
@@ -1086,8 +1143,9 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
     const int64_t pitch = (int64_t)head.N * head.K + (head.dbias ? head.N : 0);
     float* base = region[(size_t)i];
     WgradArgs a{};
-    a.dy = make_operand(it.dy, it.dy_ld, it.N, (int32_t)it.M, false);
+    a.dy = make_operand(it.dy, it.dy_ld, it.N, (int32_t)it.M, false, it.dy_half);
     a.x = make_operand(it.x, it.x_ld, it.K, (int32_t)it.M, false);
+    a.dy_half = it.dy_half ? 1 : 0;
     a.partial = base;
     a.pitch = pitch;
     a.bias_partial = head.dbias ? base + (size_t)it.N * it.K : nullptr;

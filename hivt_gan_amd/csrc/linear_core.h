@@ -86,8 +86,13 @@ enum : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_SPLIT = 2 };
 // keeps a second image of the same shape (the lo parts) PLANE_H halves behind the first.
 // MASKED = false: the caller guarantees that every element the stage loads lies inside the operand (a tile in
 // the interior, whole reduction steps), so the validity bits are neither built nor applied.
-template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, int PREC = PREC_F32, bool MASKED = true>
+// MEMH: the operand's memory holds bfloat16 values (gradients that only bf16 products consume are kept that way):
+// a piece is an 8-byte load, widened to fp32 in registers (exact) so that everything after the load is shared.
+template <int ROWS, bool TRANS, bool VEC, bool ACCUM = false, int PREC = PREC_F32, bool MASKED = true,
+          bool MEMH = false>
 struct Stage {
+  static_assert(!MEMH || (VEC && PREC == PREC_BF16), "bfloat16 memory: vector loads, bf16 products");
+  static constexpr int ELEM = MEMH ? 2 : 4;  // bytes per element in memory
   static constexpr bool BF16 = PREC != PREC_F32;
   static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
   static_assert(!SPLIT3 || TRANS, "split operands are built for [row][k] memory images only (the forward product)");
@@ -160,7 +165,11 @@ struct Stage {
       if (VEC) {
         // fast_n % 4 == 0 here: all four elements are valid or none is
         const int fast_c = fast < fast_n ? fast : fast_n - 4;
-        v[r] = *reinterpret_cast<const float4*>(op.p + (int64_t)slow_c * op.ld + fast_c);
+        if constexpr (MEMH)
+          v[r] = widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(op.p) +
+                                                       (int64_t)slow_c * op.ld + fast_c));
+        else
+          v[r] = *reinterpret_cast<const float4*>(op.p + (int64_t)slow_c * op.ld + fast_c);
         ok |= (slow_ok && fast < fast_n) ? (0xFu << (4 * r)) : 0u;
       } else {
         const float* base = op.p + (int64_t)slow_c * op.ld;
@@ -202,16 +211,23 @@ struct Stage {
         red = idx / (ROWS / 4);
         row = (idx % (ROWS / 4)) * 4;
       }
-      off[r] = (unsigned)(TRANS ? row * (int)op.ld + red : red * (int)op.ld + row) * 4u;
+      off[r] = (unsigned)(TRANS ? row * (int)op.ld + red : red * (int)op.ld + row) * (unsigned)ELEM;
     }
   }
 
   __device__ static __forceinline__ const char* origin(const Operand& op, int row0, int red0) {
-    return reinterpret_cast<const char*>(op.p + (TRANS ? (int64_t)row0 * op.ld + red0 : (int64_t)red0 * op.ld + row0));
+    return reinterpret_cast<const char*>(op.p) +
+           (TRANS ? (int64_t)row0 * op.ld + red0 : (int64_t)red0 * op.ld + row0) * ELEM;
   }
 
   __device__ static __forceinline__ int64_t step_bytes(const Operand& op) {
-    return (TRANS ? (int64_t)kBK : (int64_t)kBK * op.ld) * 4;
+    return (TRANS ? (int64_t)kBK : (int64_t)kBK * op.ld) * ELEM;
+  }
+
+  // four bfloat16 values -> fp32 (exact)
+  __device__ static __forceinline__ float4 widen(uint2 h) {
+    return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                       __uint_as_float(h.y & 0xffff0000u));
   }
 
   // every offset of a step fits 32 bits (and the int arithmetic of offsets())
@@ -222,7 +238,12 @@ struct Stage {
   __device__ __forceinline__ void fetch(const char* step_origin, const unsigned (&off)[NVEC], bool is_live) {
     live = is_live;
 #pragma unroll
-    for (int r = 0; r < NVEC; ++r) v[r] = *reinterpret_cast<const float4*>(step_origin + off[r]);
+    for (int r = 0; r < NVEC; ++r) {
+      if constexpr (MEMH)
+        v[r] = widen(*reinterpret_cast<const uint2*>(step_origin + off[r]));
+      else
+        v[r] = *reinterpret_cast<const float4*>(step_origin + off[r]);
+    }
   }
 
   // One float4 of the staged step (r < NVEC) goes to LDS; store() sends all of them.
@@ -329,17 +350,23 @@ struct Tail {
   bool residual_is_mask = false;
   float mask_scale = 1.0f;
   float mask_neg_scale = 0.0f;
+  // the result is stored as bfloat16 (nearest even): `out` points at 2-byte elements, out_ld counts elements
+  bool out_half = false;
 };
+
+__device__ __forceinline__ unsigned short to_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 
 // DEEP = 1 / 2: two / four register sets per operand, so that the global loads of steps s + 2 (.. s + 4) are
 // in flight while step s is multiplied (for grids where no other workgroup shares the compute unit to hide
 // the load latency behind; it costs registers, hence occupancy, on large grids).  With four sets a reduction
 // of 128 has all of its loads in flight at once: one memory latency per tile instead of two.
-template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, int DEEP = 0, int PREC = PREC_F32>
+// MEMH_A: operand A's memory holds bfloat16 values.
+template <int BM, int BN, bool TA, bool TB, bool VEC, bool ACC_A = false, int DEEP = 0, int PREC = PREC_F32,
+          bool MEMH_A = false>
 struct Core {
   static constexpr bool BF16 = PREC != PREC_F32;
   static constexpr bool SPLIT3 = PREC == PREC_SPLIT;
-  template <bool MASKED> using StageA = Stage<BM, TA, VEC, ACC_A, PREC, MASKED>;
+  template <bool MASKED> using StageA = Stage<BM, TA, VEC, ACC_A, PREC, MASKED, MEMH_A>;
   template <bool MASKED> using StageB = Stage<BN, TB, VEC, false, PREC, MASKED>;
   using SA = StageA<true>;   // sizes and pitches do not depend on the masking
   using SB = StageB<true>;
@@ -692,8 +719,18 @@ struct Core {
         }
       }
     }
-    float* corner = out + (int64_t)row0 * out_ld + col0;
     const int ld = (int)out_ld, off = lrow * ld + lcol;
+    if (t.out_half) {
+      unsigned short* corner = reinterpret_cast<unsigned short*>(out) + (int64_t)row0 * out_ld + col0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = off + ((r & 3) + 8 * (r >> 2)) * ld;
+        corner[o] = to_bf16_bits(v0[r]);
+        corner[o + 32] = to_bf16_bits(v1[r]);
+      }
+      return;
+    }
+    float* corner = out + (int64_t)row0 * out_ld + col0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int o = off + ((r & 3) + 8 * (r >> 2)) * ld;
@@ -783,8 +820,14 @@ struct Core {
             v1 += res1[r];
           }
         }
-        if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
-        if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
+        if (t.out_half) {
+          unsigned short* o16 = reinterpret_cast<unsigned short*>(out);
+          if (ok0) o16[(int64_t)gr * out_ld + c0] = to_bf16_bits(v0);
+          if (ok1) o16[(int64_t)gr * out_ld + c1] = to_bf16_bits(v1);
+        } else {
+          if (ok0) out[(int64_t)gr * out_ld + c0] = v0;
+          if (ok1) out[(int64_t)gr * out_ld + c1] = v1;
+        }
       }
     }
   }
@@ -792,7 +835,9 @@ struct Core {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-inline Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans) {
+// half: the memory holds bfloat16 values (p is then a pointer to 2-byte elements in disguise, ld counts elements;
+// four of them are one 8-byte vector load)
+inline Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t red, bool trans, bool half = false) {
   Operand o;
   o.p = p;
   o.ld = ld;
@@ -800,7 +845,8 @@ inline Operand make_operand(const float* p, int64_t ld, int32_t rows, int32_t re
   o.red = red;
   // vector loads run along the contiguous dimension: the reduction if trans, else the row index
   const int32_t fast_n = trans ? red : rows;
-  o.vec_ok = (aligned16(p) && ld % 4 == 0 && fast_n % 4 == 0 && fast_n >= 4) ? 1 : 0;
+  const bool aligned = half ? (reinterpret_cast<uintptr_t>(p) & 7) == 0 : aligned16(p);
+  o.vec_ok = (aligned && ld % 4 == 0 && fast_n % 4 == 0 && fast_n >= 4) ? 1 : 0;
   return o;
 }
 

@@ -569,6 +569,18 @@ def _pass_through_grad(dy: torch.Tensor, shape, to_leaf: bool) -> torch.Tensor:
     return g.clone() if to_leaf else g
 
 
+_matmul_mask = 0  # what set_matmul_precision last set
+
+
+def _half_gradients() -> bool:
+    """True while both backward products round their operands to bfloat16: a gradient that only those products
+    read may then be kept in memory as bfloat16 (the rounding happens where it is written instead of where it is
+    read; the products see the same values)."""
+    return (_matmul_mask & 6) == 6
+
+
+HALF_DY, HALF_DX = 1, 2
+
 _PRECISIONS = {"fp32": 0, "bf16": 14, "bf16-plain": 7, "bf16-fwd": 1, "bf16-bwd": 6, "bf16-split-fwd": 8}
 
 
@@ -578,9 +590,11 @@ def set_matmul_precision(precision: str) -> str:
     ``"fp32"`` (default): exact fp32 products.  ``"bf16"``: operands of every dense product (forward,
     data gradient, weight gradient) rounded to bfloat16, fp32 accumulation.  ``"bf16-fwd-dgrad"`` /
     ``"bf16-fwd"``: only those products take bf16 operands, the others stay exact."""
+    global _matmul_mask
     if precision not in _PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
     prev = _lib.value("hivt_set_matmul_bf16", _PRECISIONS[precision])
+    _matmul_mask = _PRECISIONS[precision]
     for name, mask in _PRECISIONS.items():
         if mask == prev:
             return name
@@ -674,8 +688,10 @@ def _all_leaves(*tensors) -> bool:
 
 def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int, n: int, k: int, dev,
                  bias: bool = True, leaves: bool = False):
-    """``(dW [n, k], db [n] or None)`` of ``y = x W^T + b`` from ``g = dL/dy`` [m, n] and ``x`` [m, k].
-    ``leaves``: weight and bias are leaves of the graph, so the product may be deferred."""
+    """``(dW [n, k], db [n] or None)`` of ``y = x W^T + b`` from ``g = dL/dy`` [m, n] (fp32, or bfloat16 while
+    ``_half_gradients()``) and ``x`` [m, k].  ``leaves``: weight and bias are leaves of the graph, so the product
+    may be deferred."""
+    half = g.dtype == torch.bfloat16
     dw = torch.empty(n, k, dtype=torch.float32, device=dev)
     db = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
     if leaves and _deferred is not None and m > 0:
@@ -684,9 +700,13 @@ def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int,
         # addresses, not tensors, of the results: autograd takes a gradient over only while it holds the one
         # reference to it
         _deferred.append(([g.data_ptr(), g_ld, x.data_ptr(), x_ld, m, n, k, dw.data_ptr(),
-                           db.data_ptr() if bias else 0, 0], dev, (g, x)))
+                           db.data_ptr() if bias else 0, 4 if half else 0], dev, (g, x)))
         return dw, db
     ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
+    if half:
+        _lib.call("hivt_linear_wgrad_half", _p(g), g_ld, _p(x), x_ld, m, n, k, _p(dw), _p(db), _p(ws), ws.numel(),
+                  HALF_DY, _stream(g))
+        return dw, db
     _lib.call("hivt_linear_wgrad", _p(g), g_ld, _p(x), x_ld, m, n, k, _p(dw), _p(db), _p(ws), ws.numel(), _stream(g))
     return dw, db
 
@@ -1546,13 +1566,24 @@ class _PreNormFeedForward(torch.autograd.Function):
             dz2 = dy2
         # second Linear: weight gradient, then the data gradient gated by the ReLU / dropout of its input
         dw2, db2 = _weight_grad(dz2, dz2.stride(0), h, hdim, m, d, hdim, dev, leaves=ctx.param_leaves)
-        dz1 = torch.empty(m, hdim, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
-                  1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
+        # the hidden gradient is read by two bf16 products and nothing else: bfloat16 in memory when they are on
+        half = _half_gradients() and hdim % 4 == 0 and d % 4 == 0
+        dz1 = torch.empty(m, hdim, dtype=torch.bfloat16 if half else torch.float32, device=dev)
+        dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
+        if half:
+            _lib.call("hivt_linear_bwd_data_half", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
+                      1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, HALF_DX, s)
+        else:
+            _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
+                      1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
         # first Linear
         dw1, db1 = _weight_grad(dz1, hdim, xn, d, m, hdim, d, dev, leaves=ctx.param_leaves)
-        dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0, _p(dxn), d, s)
+        if half:
+            _lib.call("hivt_linear_bwd_data_half", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0,
+                      _p(dxn), d, HALF_DY, s)
+        else:
+            _lib.call("hivt_linear_bwd_data", _p(dz1), hdim, _p(w1), w1.stride(0), m, hdim, d, None, 0, 1.0, None, 0,
+                      _p(dxn), d, s)
         # LayerNorm, plus the residual route's gradient (dy itself)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
         dgamma, dbeta = _ln_backward(dxn, x2, x2.stride(0), stats, gamma, beta, 0, m, d, dy2, dx, s, ctx.norm_leaves)

@@ -333,6 +333,23 @@ int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, co
                 int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
                 size_t workspace_bytes, hivt_stream_t stream);
 
+/* Gradients that only bf16 products consume may live in memory as bfloat16: those products round their operands to
+ * bfloat16 when they stage them, so storing the rounded values changes no product and halves the bytes.  Valid
+ * only while the data-gradient (weight-gradient) products are in bf16 mode (hivt_set_matmul_bf16).
+ * hivt_linear_bwd_data_half: hivt_linear_bwd_data with dy read as bfloat16 [M,N] (HIVT_HALF_DY) and / or dx written
+ * as bfloat16 [M,K] (HIVT_HALF_DX; rounded to nearest even after the mask / add epilogue); leading dimensions
+ * count elements, rows start on 8-byte boundaries. */
+#define HIVT_HALF_DY 1
+#define HIVT_HALF_DX 2
+int hivt_linear_bwd_data_half(const void* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
+                              int32_t K, const float* mask, int64_t mask_ld, float mask_scale, const float* add,
+                              int64_t add_ld, void* dx, int64_t dx_ld, int32_t half_flags, hivt_stream_t stream);
+/* hivt_linear_wgrad with dy read as bfloat16 [M,N] (half_flags = HIVT_HALF_DY); the bias gradient is then the sum
+ * of the rounded values.  In hivt_linear_wgrad_group the same is bit 2 of an item's flags. */
+int hivt_linear_wgrad_half(const void* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
+                           int32_t K, float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                           int32_t half_flags, hivt_stream_t stream);
+
 /* Rows of partial sums hivt_ln_bwd leaves for M input rows (0 for M == 0). */
 size_t hivt_ln_bwd_partial_rows(int64_t M);
 

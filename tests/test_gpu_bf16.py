@@ -172,3 +172,123 @@ def test_bf16_mode_full_step_close_to_fp32_and_switch_restores_exact_mode():
         # rounding of the products itself does (the critics have no such selection)
         bound = (2e-2, 0.9995) if group == "critic" else (0.15, 0.99)
         assert l2 < bound[0] and cos > bound[1], (group, l2, cos)
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients kept in memory as bfloat16 between the bf16 backward products
+# ---------------------------------------------------------------------------------------------
+from hivt_gan_amd import _lib  # noqa: E402
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None  # plain integers: what the binding takes for device addresses
+
+
+@pytest.mark.parametrize("M,N,K,mask", [(3000, 512, 128, False), (52_000, 128, 512, True), (2623, 384, 128, False),
+                                        (100, 128, 64, False), (70_001, 128, 128, True)])
+def test_data_gradient_reads_and_writes_bfloat16_memory(M, N, K, mask):
+    """The bf16 data-gradient product rounds dy to bfloat16 when it stages it: handing it the rounded values in
+    bfloat16 memory gives the same dx bit for bit, and a bfloat16 dx is the fp32 result rounded to nearest even."""
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(M + N)
+        dy = torch.randn(M, N, device=DEV)
+        w = torch.randn(N, K, device=DEV) / N ** 0.5
+        gate = torch.relu(torch.randn(M, K, device=DEV)) if mask else None
+        s = torch.cuda.current_stream().cuda_stream
+        ref = torch.empty(M, K, device=DEV)
+        _lib.call("hivt_linear_bwd_data", _ptr(dy), N, _ptr(w), K, M, N, K, _ptr(gate), K, 1.25, None, 0, _ptr(ref), K, s)
+        dyh = dy.bfloat16()
+        got = torch.empty(M, K, device=DEV)
+        _lib.call("hivt_linear_bwd_data_half", _ptr(dyh), N, _ptr(w), K, M, N, K, _ptr(gate), K, 1.25, None, 0, _ptr(got),
+                  K, ops.HALF_DY, s)
+        assert torch.equal(got, ref)
+        goth = torch.empty(M, K, device=DEV, dtype=torch.bfloat16)
+        _lib.call("hivt_linear_bwd_data_half", _ptr(dyh), N, _ptr(w), K, M, N, K, _ptr(gate), K, 1.25, None, 0, _ptr(goth),
+                  K, ops.HALF_DY | ops.HALF_DX, s)
+        assert torch.equal(goth, ref.bfloat16())
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 512, 128), (52_000, 128, 512), (2623, 384, 128), (100, 128, 64),
+                                   (300_000, 128, 128)])
+def test_weight_gradient_reads_bfloat16_memory(M, N, K):
+    """Same for the weight gradient, single and grouped: dw from bfloat16 dy equals dw from the fp32 tensor holding
+    the same (rounded) values bit for bit, and so does the bias gradient."""
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        torch.manual_seed(M + K)
+        dyh = torch.randn(M, N, device=DEV).bfloat16()
+        dy = dyh.float()
+        x = torch.randn(M, K, device=DEV)
+        s = torch.cuda.current_stream().cuda_stream
+        ws = torch.empty(_lib.query("hivt_linear_wgrad_workspace_bytes", M, N, K), dtype=torch.uint8, device=DEV)
+        ref_w, ref_b = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        _lib.call("hivt_linear_wgrad", _ptr(dy), N, _ptr(x), K, M, N, K, _ptr(ref_w), _ptr(ref_b), _ptr(ws), ws.numel(), s)
+        got_w, got_b = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        _lib.call("hivt_linear_wgrad_half", _ptr(dyh), N, _ptr(x), K, M, N, K, _ptr(got_w), _ptr(got_b), _ptr(ws),
+                  ws.numel(), ops.HALF_DY, s)
+        assert torch.equal(got_w, ref_w) and torch.equal(got_b, ref_b)
+        # grouped: the same term twice, once from each kind of memory
+        g_w = [torch.empty(N, K, device=DEV) for _ in range(2)]
+        g_b = [torch.empty(N, device=DEV) for _ in range(2)]
+        flat = [dy.data_ptr(), N, x.data_ptr(), K, M, N, K, g_w[0].data_ptr(), g_b[0].data_ptr(), 0,
+                dyh.data_ptr(), N, x.data_ptr(), K, M, N, K, g_w[1].data_ptr(), g_b[1].data_ptr(), 4]
+        ops._launch_wgrad_group(flat, 2, DEV)
+        assert torch.equal(g_w[0], g_w[1]) and torch.equal(g_b[0], g_b[1])
+        assert rel(g_w[1], ref_w) < 1e-5
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+def test_bfloat16_memory_operands_are_refused_in_exact_mode():
+    prev = ops.set_matmul_precision("fp32")
+    try:
+        M, N, K = 256, 128, 128
+        dyh = torch.randn(M, N, device=DEV).bfloat16()
+        w, x = torch.randn(N, K, device=DEV), torch.randn(M, K, device=DEV)
+        out = torch.empty(M, K, device=DEV)
+        s = torch.cuda.current_stream().cuda_stream
+        with pytest.raises(_lib.HivtLibraryError):
+            _lib.call("hivt_linear_bwd_data_half", _ptr(dyh), N, _ptr(w), K, M, N, K, None, 0, 1.0, None, 0, _ptr(out), K,
+                      ops.HALF_DY, s)
+        ws = torch.empty(_lib.query("hivt_linear_wgrad_workspace_bytes", M, N, K), dtype=torch.uint8, device=DEV)
+        dw = torch.empty(N, K, device=DEV)
+        with pytest.raises(_lib.HivtLibraryError):
+            _lib.call("hivt_linear_wgrad_half", _ptr(dyh), N, _ptr(x), K, M, N, K, _ptr(dw), None, _ptr(ws), ws.numel(),
+                      ops.HALF_DY, s)
+    finally:
+        ops.set_matmul_precision(prev)
+
+
+def test_feed_forward_block_with_bfloat16_hidden_gradient_matches_the_fp32_memory_path():
+    """In "bf16" mode the feed-forward block keeps its hidden gradient as bfloat16; every product sees the values
+    it saw before, so all gradients but the hidden layer's bias gradient (now a sum of rounded values) keep their
+    bits."""
+    torch.manual_seed(5)
+    M, D = 5000, 128
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    lin1, lin2 = torch.nn.Linear(D, 4 * D).to(DEV), torch.nn.Linear(4 * D, D).to(DEV)
+    x = torch.randn(M, D, device=DEV, requires_grad=True)
+    gy = torch.randn(M, D, device=DEV)
+    params = [x, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+
+    def grads():
+        for p in params:
+            p.grad = None
+        ops.pre_norm_feed_forward(x, norm, lin1, 0.0, lin2, 0.0, True).backward(gy)
+        return [p.grad.clone() for p in params]
+
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        half = grads()
+        ops._matmul_mask = 0  # the library stays in bf16 mode, the block falls back to fp32 memory
+        full = grads()
+    finally:
+        ops.set_matmul_precision(prev)
+    for i, (a, b) in enumerate(zip(half, full)):
+        if i == 4:
+            assert rel(a, b) < TOL / 4
+        else:
+            assert torch.equal(a, b), i

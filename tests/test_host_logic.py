@@ -218,6 +218,19 @@ def test_generated_binding_covers_the_same_entry_points():
     assert fast.hivt_linear_fwd(*args) is None
 
 
+def test_generated_binding_refuses_ctypes_pointer_objects():
+    """A ``c_void_p`` exposes the eight host bytes holding the address as a buffer; taken as a host table it would
+    hand a kernel a host address.  The binding takes ints, None and arrays of numbers only."""
+    fast = _lib._load_fast()
+    if not fast:
+        pytest.skip("the generated binding is not built")
+    with pytest.raises(TypeError):
+        fast.hivt_linear_wgrad_group(ctypes.c_void_p(64), 0, None, 0, None)
+    with pytest.raises(TypeError):
+        fast.hivt_linear_wgrad_group(ctypes.pointer(ctypes.c_int64(0)), 0, None, 0, None)
+    assert fast.hivt_linear_wgrad_group((ctypes.c_int64 * 10)(), 0, None, 0, None) is None  # no terms: no GPU work
+
+
 def test_kernels_refuse_cpu_tensors():
     from hivt_gan_amd import ops
     with pytest.raises(RuntimeError, match="GPU only"):
