@@ -49,6 +49,8 @@ SIGNATURES = {
                                 c_int64, _P, _P]),
     "hivt_dropout_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_uint64, _P, c_int64, c_int32, _P,
                                  c_int64, _P]),
+    "hivt_dropout_bwd_half": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_uint64, _P, c_int64, c_int32, _P,
+                                      c_int64, _P]),
     "hivt_rowsum_by_code_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_rowsum_by_code": (c_int, [_P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "hivt_linear_bwd_data": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_float, _P,
@@ -70,6 +72,8 @@ SIGNATURES = {
     "hivt_temporal_attn_fwd": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P]),
     "hivt_temporal_attn_bwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P, _P,
                                        _P]),
+    "hivt_temporal_attn_bwd_half": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_float, c_uint64, _P,
+                                            _P, _P]),
     "hivt_laplace_workspace_bytes": (c_size_t, [c_int32]),
     "hivt_laplace_minmode_fwd": (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P,
                                          _P, c_size_t, _P]),

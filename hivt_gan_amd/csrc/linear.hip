@@ -689,6 +689,49 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restric
   }
 }
 
+// The same, four consecutive columns per thread (N, the leading dimensions and the addresses allow 16-byte
+// accesses); HALF_OUT: dz is bfloat16 in memory (8-byte stores), values rounded to nearest even.
+template <bool HALF_OUT>
+__global__ __launch_bounds__(256) void dropout_bwd_vec4_kernel(const float* __restrict__ dy, int64_t dy_ld,
+                                                               const float* __restrict__ y, int64_t y_ld, int relu,
+                                                               float p, uint64_t seed_host,
+                                                               const uint64_t* __restrict__ seed_ptr, int64_t M, int N,
+                                                               void* __restrict__ dz, int64_t dz_ld) {
+  const float scale = 1.0f / (1.0f - p);
+  const uint64_t seed = seed_host + (seed_ptr != nullptr ? *seed_ptr : 0ull);
+  const int n4 = N / 4;
+  const int64_t total = M * (int64_t)n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / n4;
+    const int c = (int)(i - m * n4) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(dy + m * dy_ld + c);
+    bool k0, k1, k2, k3;
+    if (relu) {
+      const float4 t = *reinterpret_cast<const float4*>(y + m * y_ld + c);
+      k0 = t.x > 0.0f; k1 = t.y > 0.0f; k2 = t.z > 0.0f; k3 = t.w > 0.0f;
+    } else {
+      const uint64_t e = (uint64_t)(m * N + c);
+      k0 = p <= 0.0f || dropout_uniform(seed, e + 0) >= p;
+      k1 = p <= 0.0f || dropout_uniform(seed, e + 1) >= p;
+      k2 = p <= 0.0f || dropout_uniform(seed, e + 2) >= p;
+      k3 = p <= 0.0f || dropout_uniform(seed, e + 3) >= p;
+    }
+    float4 r;
+    r.x = k0 ? g.x * scale : 0.0f;
+    r.y = k1 ? g.y * scale : 0.0f;
+    r.z = k2 ? g.z * scale : 0.0f;
+    r.w = k3 ? g.w * scale : 0.0f;
+    if constexpr (HALF_OUT) {
+      uint2 h;
+      h.x = (unsigned)to_bf16_bits(r.x) | ((unsigned)to_bf16_bits(r.y) << 16);
+      h.y = (unsigned)to_bf16_bits(r.z) | ((unsigned)to_bf16_bits(r.w) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dz) + m * dz_ld + c) = h;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(dz) + m * dz_ld + c) = r;
+    }
+  }
+}
+
 // Operand precision of the three products: 0 = fp32 (exact), 1 = bfloat16 operands with fp32 accumulation.
 // Process-wide, set through hivt_set_matmul_bf16(); read once per call on the host.
 std::atomic<int> g_matmul_bf16{0};
@@ -1342,18 +1385,44 @@ extern "C" int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* 
   return HIVT_OK;
 }
 
-extern "C" int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
-                                uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz,
-                                int64_t dz_ld, hivt_stream_t stream) {
+static int dropout_bwd_impl(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
+                            uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, void* dz, int64_t dz_ld,
+                            bool half_out, hivt_stream_t stream) {
   const char* what = "hivt_dropout_bwd";
   HIVT_REQUIRE(M >= 0 && N > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
   HIVT_REQUIRE(dropout_p >= 0.0f && dropout_p < 1.0f, HIVT_ERR_ARG, "%s: dropout_p must be in [0,1)", what);
   if (M == 0) return HIVT_OK;
   HIVT_REQUIRE(dy && dz && (!relu || y), HIVT_ERR_ARG, "%s: null pointer", what);
-  int64_t blocks = (M * (int64_t)N + 1023) / 1024;
+  const bool wide = N % 4 == 0 && dy_ld % 4 == 0 && dz_ld % 4 == 0 && aligned16(dy) &&
+                    (half_out ? (reinterpret_cast<uintptr_t>(dz) & 7) == 0 : aligned16(dz)) &&
+                    (!relu || (y_ld % 4 == 0 && aligned16(y)));
+  HIVT_REQUIRE(wide || !half_out, HIVT_ERR_ARG,
+               "%s: a bfloat16 dz needs a column count and leading dimensions that are multiples of 4 and aligned rows",
+               what);
+  int64_t blocks = (M * (int64_t)N / (wide ? 4 : 1) + 1023) / 1024;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld,
-                     relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld);
+  if (blocks < 1) blocks = 1;
+  if (wide && half_out)
+    hipLaunchKernelGGL(dropout_bwd_vec4_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       y, y_ld, relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld);
+  else if (wide)
+    hipLaunchKernelGGL(dropout_bwd_vec4_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld,
+                       y, y_ld, relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld);
+  else
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_ld, y, y_ld,
+                       relu, dropout_p, seed, seed_ptr, M, N, reinterpret_cast<float*>(dz), dz_ld);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
+                                uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz,
+                                int64_t dz_ld, hivt_stream_t stream) {
+  return dropout_bwd_impl(dy, dy_ld, y, y_ld, relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld, false, stream);
+}
+
+extern "C" int hivt_dropout_bwd_half(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu,
+                                     float dropout_p, uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N,
+                                     void* dz, int64_t dz_ld, hivt_stream_t stream) {
+  return dropout_bwd_impl(dy, dy_ld, y, y_ld, relu, dropout_p, seed, seed_ptr, M, N, dz, dz_ld, true, stream);
 }

@@ -17,12 +17,15 @@ namespace {
 
 constexpr int kMaxS = 32;
 
+__device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 struct TAttnArgs {
   const float* qkv;   // [S, N, 3D]
   float* out;         // [S, N, D]
   float* lse;         // [N, H, S]  log-sum-exp of the scaled scores per query
   const float* d_out; // backward
   float* d_qkv;       // backward [S, N, 3D]
+  int32_t d_qkv_half; // d_qkv points at bfloat16 elements (values rounded to nearest even)
   int32_t S, N, H;
   float scale;
   float dropout_p;
@@ -215,7 +218,16 @@ __global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const TAttnArgs 
   __syncthreads();
   for (int i = threadIdx.x; i < S * (ROW / 4); i += 256) {
     const int s = i / (ROW / 4), c = (i % (ROW / 4)) * 4;
-    *reinterpret_cast<float4*>(a.d_qkv + ((int64_t)s * N + n) * ROW + c) = *reinterpret_cast<const float4*>(qkv + s * ROW + c);
+    const float4 g = *reinterpret_cast<const float4*>(qkv + s * ROW + c);
+    const int64_t at = ((int64_t)s * N + n) * ROW + c;
+    if (a.d_qkv_half) {
+      uint2 h;
+      h.x = (unsigned)bf16_bits(g.x) | ((unsigned)bf16_bits(g.y) << 16);
+      h.y = (unsigned)bf16_bits(g.z) | ((unsigned)bf16_bits(g.w) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.d_qkv) + at) = h;
+    } else {
+      *reinterpret_cast<float4*>(a.d_qkv + at) = g;
+    }
   }
 }
 
@@ -282,9 +294,9 @@ extern "C" int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, in
   return HIVT_OK;
 }
 
-extern "C" int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse,
-                                      int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                                      const uint64_t* seed_ptr, float* d_qkv, hivt_stream_t stream) {
+static int temporal_attn_bwd_impl(const float* d_out, const float* qkv, const float* out, const float* lse, int32_t S,
+                                  int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                  const uint64_t* seed_ptr, float* d_qkv, bool d_qkv_half, hivt_stream_t stream) {
   const char* what = "hivt_temporal_attn_bwd";
   int rc = check(what, S, N, D, H, dropout_p);
   if (rc != HIVT_OK) return rc;
@@ -292,10 +304,24 @@ extern "C" int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, cons
   HIVT_REQUIRE(d_out && qkv && out && lse && d_qkv, HIVT_ERR_ARG, "%s: null pointer", what);
   TAttnArgs a{};
   a.qkv = qkv; a.out = const_cast<float*>(out); a.lse = const_cast<float*>(lse); a.d_out = d_out; a.d_qkv = d_qkv;
+  a.d_qkv_half = d_qkv_half ? 1 : 0;
   a.S = S; a.N = N; a.H = H;
   a.scale = 1.0f / sqrtf((float)(D / H)); a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   HIVT_REQUIRE(dispatch(D, H, true, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG, "%s: no kernel for D=%d H=%d", what, D,
                H);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse,
+                                      int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                      const uint64_t* seed_ptr, float* d_qkv, hivt_stream_t stream) {
+  return temporal_attn_bwd_impl(d_out, qkv, out, lse, S, N, D, H, dropout_p, seed, seed_ptr, d_qkv, false, stream);
+}
+
+extern "C" int hivt_temporal_attn_bwd_half(const float* d_out, const float* qkv, const float* out, const float* lse,
+                                           int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                           const uint64_t* seed_ptr, void* d_qkv, hivt_stream_t stream) {
+  return temporal_attn_bwd_impl(d_out, qkv, out, lse, S, N, D, H, dropout_p, seed, seed_ptr,
+                                reinterpret_cast<float*>(d_qkv), true, stream);
 }

@@ -1559,20 +1559,25 @@ class _PreNormFeedForward(torch.autograd.Function):
         dev = x2.device
         s = _stream(x2)
         dy2 = _rows2(dy)
-        if p2 > 0.0:
+        # gradients that only the two bf16 products read: bfloat16 in memory while those are on
+        half = _half_gradients() and hdim % 4 == 0 and d % 4 == 0
+        half2 = half and p2 > 0.0 and dy2.stride(0) % 4 == 0 and dy2.data_ptr() % 16 == 0
+        if half2:
+            dz2 = torch.empty(m, d, dtype=torch.bfloat16, device=dev)
+            _lib.call("hivt_dropout_bwd_half", _p(dy2), dy2.stride(0), None, 0, 0, p2, seed2, _p(seed_dev), m, d, _p(dz2),
+                      d, s)
+        elif p2 > 0.0:
             dz2 = torch.empty(m, d, dtype=torch.float32, device=dev)
             _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), None, 0, 0, p2, seed2, _p(seed_dev), m, d, _p(dz2), d, s)
         else:
             dz2 = dy2
         # second Linear: weight gradient, then the data gradient gated by the ReLU / dropout of its input
         dw2, db2 = _weight_grad(dz2, dz2.stride(0), h, hdim, m, d, hdim, dev, leaves=ctx.param_leaves)
-        # the hidden gradient is read by two bf16 products and nothing else: bfloat16 in memory when they are on
-        half = _half_gradients() and hdim % 4 == 0 and d % 4 == 0
         dz1 = torch.empty(m, hdim, dtype=torch.bfloat16 if half else torch.float32, device=dev)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
         if half:
             _lib.call("hivt_linear_bwd_data_half", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
-                      1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, HALF_DX, s)
+                      1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, HALF_DX | (HALF_DY if half2 else 0), s)
         else:
             _lib.call("hivt_linear_bwd_data", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
                       1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, s)
@@ -1654,7 +1659,14 @@ class _PreNormTemporalAttention(torch.autograd.Function):
         dev = x2.device
         st = _stream(x2)
         dy2 = _rows2(dy)
-        if p_out > 0.0:
+        # gradients that only the bf16 products read (the dropout's, the attention's): bfloat16 in memory
+        half = _half_gradients() and d % 4 == 0
+        half_z = half and p_out > 0.0 and dy2.stride(0) % 4 == 0 and dy2.data_ptr() % 16 == 0
+        if half_z:
+            dz = torch.empty(m, d, dtype=torch.bfloat16, device=dev)
+            _lib.call("hivt_dropout_bwd_half", _p(dy2), dy2.stride(0), None, 0, 0, p_out, seed_out, _p(seed_dev), m, d,
+                      _p(dz), d, st)
+        elif p_out > 0.0:
             dz = torch.empty(m, d, dtype=torch.float32, device=dev)
             _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), None, 0, 0, p_out, seed_out, _p(seed_dev), m, d, _p(dz),
                       d, st)
@@ -1662,15 +1674,23 @@ class _PreNormTemporalAttention(torch.autograd.Function):
             dz = dy2
         dw_out, db_out = _weight_grad(dz, dz.stride(0), o, d, m, d, d, dev, leaves=ctx.param_leaves)
         do = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, None, 0,
-                  _p(do), d, st)
-        dqkv = torch.empty(m, 3 * d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_temporal_attn_bwd", _p(do), _p(qkv), _p(o), _p(lse), s_len, n, d, num_heads, p_attn, seed_attn,
-                  _p(seed_dev), _p(dqkv), st)
+        if half_z:
+            _lib.call("hivt_linear_bwd_data_half", _p(dz), d, _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0, None, 0,
+                      _p(do), d, HALF_DY, st)
+        else:
+            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w_out), w_out.stride(0), m, d, d, None, 0, 1.0,
+                      None, 0, _p(do), d, st)
+        dqkv = torch.empty(m, 3 * d, dtype=torch.bfloat16 if half else torch.float32, device=dev)
+        _lib.call("hivt_temporal_attn_bwd_half" if half else "hivt_temporal_attn_bwd", _p(do), _p(qkv), _p(o), _p(lse),
+                  s_len, n, d, num_heads, p_attn, seed_attn, _p(seed_dev), _p(dqkv), st)
         dw_in, db_in = _weight_grad(dqkv, 3 * d, xn, d, m, 3 * d, d, dev, leaves=ctx.param_leaves)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
-        _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, None, 0,
-                  _p(dxn), d, st)
+        if half:
+            _lib.call("hivt_linear_bwd_data_half", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0,
+                      None, 0, _p(dxn), d, HALF_DY, st)
+        else:
+            _lib.call("hivt_linear_bwd_data", _p(dqkv), 3 * d, _p(w_in), w_in.stride(0), m, 3 * d, d, None, 0, 1.0, None,
+                      0, _p(dxn), d, st)
         dx = torch.empty(m, d, dtype=torch.float32, device=dev)
         dgamma, dbeta = _ln_backward(dxn, x2, x2.stride(0), stats, gamma, beta, 0, m, d, dy2, dx, st, ctx.norm_leaves)
         return (dx.view(s_len, n, d), dgamma, dbeta, None, dw_in, db_in, dw_out, db_out, None, None, None, None, None)

@@ -275,6 +275,11 @@ int hivt_linear_fwd(const float* x, int64_t x_ld, const float* w, int64_t w_ld, 
 int hivt_dropout_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
                      uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, float* dz, int64_t dz_ld,
                      hivt_stream_t stream);
+/* The same with dz stored as bfloat16 [M,N] (nearest even; dz_ld in elements): for a dz that only bf16 products
+ * read (see hivt_linear_bwd_data_half).  N and the leading dimensions must be multiples of 4, rows aligned. */
+int hivt_dropout_bwd_half(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int relu, float dropout_p,
+                          uint64_t seed, const uint64_t* seed_ptr, int64_t M, int32_t N, void* dz, int64_t dz_ld,
+                          hivt_stream_t stream);
 
 /* dx[M,K] = dy[M,N] w[N,K]  (gradient of hivt_linear_fwd w.r.t. x for the plain epilogue).
  * mask (may be NULL, [M,K] with row stride mask_ld): x was itself the output of a ReLU [+ dropout] epilogue,
@@ -378,6 +383,11 @@ int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, int32_t D, in
 int hivt_temporal_attn_bwd(const float* d_out, const float* qkv, const float* out, const float* lse, int32_t S,
                            int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
                            float* d_qkv, hivt_stream_t stream);
+/* The same with d_qkv stored as bfloat16 [S,N,3D] (nearest even): its only readers are the input projection's
+ * two gradient products, which round it to bfloat16 anyway while they run in bf16 mode. */
+int hivt_temporal_attn_bwd_half(const float* d_out, const float* qkv, const float* out, const float* lse, int32_t S,
+                                int32_t N, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                const uint64_t* seed_ptr, void* d_qkv, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused regression / classification loss (min over modes + Laplace NLL + soft-target CE)

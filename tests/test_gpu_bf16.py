@@ -262,10 +262,28 @@ def test_bfloat16_memory_operands_are_refused_in_exact_mode():
         ops.set_matmul_precision(prev)
 
 
-def test_feed_forward_block_with_bfloat16_hidden_gradient_matches_the_fp32_memory_path():
-    """In "bf16" mode the feed-forward block keeps its hidden gradient as bfloat16; every product sees the values
-    it saw before, so all gradients but the hidden layer's bias gradient (now a sum of rounded values) keep their
-    bits."""
+def _half_vs_full(grads, loose):
+    """Gradients of a block with bfloat16 intermediates against the same block on fp32 memory (library in "bf16"
+    mode both times): equal bit for bit except the bias gradients listed in ``loose``, which become sums of
+    rounded values."""
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        half = grads()
+        ops._matmul_mask = 0  # the library stays in bf16 mode, the block falls back to fp32 memory
+        full = grads()
+    finally:
+        ops.set_matmul_precision(prev)
+    for i, (a, b) in enumerate(zip(half, full)):
+        if i in loose:
+            assert rel(a, b) < TOL / 4, i
+        else:
+            assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_feed_forward_block_with_bfloat16_gradients_matches_the_fp32_memory_path(p):
+    """In "bf16" mode the feed-forward block keeps its hidden gradient (and the gradient behind its output dropout)
+    as bfloat16; every product sees the values it saw before."""
     torch.manual_seed(5)
     M, D = 5000, 128
     norm = torch.nn.LayerNorm(D).to(DEV)
@@ -275,20 +293,71 @@ def test_feed_forward_block_with_bfloat16_hidden_gradient_matches_the_fp32_memor
     params = [x, norm.weight, norm.bias, lin1.weight, lin1.bias, lin2.weight, lin2.bias]
 
     def grads():
-        for p in params:
-            p.grad = None
-        ops.pre_norm_feed_forward(x, norm, lin1, 0.0, lin2, 0.0, True).backward(gy)
-        return [p.grad.clone() for p in params]
+        torch.manual_seed(11)  # the dropout seeds
+        for q in params:
+            q.grad = None
+        ops.pre_norm_feed_forward(x, norm, lin1, p, lin2, p, True).backward(gy)
+        return [q.grad.clone() for q in params]
 
-    prev = ops.set_matmul_precision("bf16")
-    try:
-        half = grads()
-        ops._matmul_mask = 0  # the library stays in bf16 mode, the block falls back to fp32 memory
-        full = grads()
-    finally:
-        ops.set_matmul_precision(prev)
-    for i, (a, b) in enumerate(zip(half, full)):
-        if i == 4:
-            assert rel(a, b) < TOL / 4
-        else:
-            assert torch.equal(a, b), i
+    _half_vs_full(grads, loose=(4, 6) if p > 0 else (4,))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_temporal_attention_block_with_bfloat16_gradients_matches_the_fp32_memory_path(p):
+    torch.manual_seed(6)
+    S, N, D = 21, 300, 128
+    norm = torch.nn.LayerNorm(D).to(DEV)
+    mha = torch.nn.MultiheadAttention(D, 8, dropout=p).to(DEV)
+    x = torch.randn(S, N, D, device=DEV, requires_grad=True)
+    gy = torch.randn(S, N, D, device=DEV)
+    params = [x, norm.weight, norm.bias, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias]
+
+    def grads():
+        torch.manual_seed(12)
+        for q in params:
+            q.grad = None
+        ops.pre_norm_temporal_attention(x, norm, mha, p, True).backward(gy)
+        return [q.grad.clone() for q in params]
+
+    _half_vs_full(grads, loose=(4, 6) if p > 0 else (4,))
+
+
+@pytest.mark.parametrize("M,N,relu", [(5000, 128, False), (333, 64, True), (70_001, 128, False), (1, 4, False)])
+def test_dropout_backward_writes_bfloat16(M, N, relu):
+    torch.manual_seed(M)
+    dy = torch.randn(M, N, device=DEV)
+    y = torch.relu(torch.randn(M, N, device=DEV)) if relu else None
+    s = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(M, N, device=DEV)
+    got = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    for name, out in (("hivt_dropout_bwd", ref), ("hivt_dropout_bwd_half", got)):
+        _lib.call(name, _ptr(dy), N, _ptr(y), N, int(relu), 0.25, 1234, None, M, N, _ptr(out), N, s)
+    assert torch.equal(got, ref.bfloat16())
+    # the one-element-per-thread kernel (taken when a leading dimension rules out 16-byte accesses) agrees
+    padded = torch.zeros(M, N + 1, device=DEV)
+    padded[:, :N] = dy
+    slow = torch.empty(M, N, device=DEV)
+    _lib.call("hivt_dropout_bwd", _ptr(padded), N + 1, _ptr(y), N, int(relu), 0.25, 1234, None, M, N, _ptr(slow), N, s)
+    assert torch.equal(slow, ref)
+    kept = float((ref != 0).float().mean())
+    assert (0.45 < kept < 0.55) if relu else (0.72 < kept < 0.78)
+    # an odd column count has no bfloat16 form
+    with pytest.raises(_lib.HivtLibraryError):
+        _lib.call("hivt_dropout_bwd_half", _ptr(dy), N, None, 0, 0, 0.25, 1234, None, M, 3, _ptr(got), N, s)
+
+
+def test_temporal_attention_backward_writes_bfloat16():
+    torch.manual_seed(9)
+    S, N, D, H = 21, 257, 128, 8
+    qkv = torch.randn(S, N, 3 * D, device=DEV)
+    o = torch.empty(S, N, D, device=DEV)
+    lse = torch.empty(N, H, S, device=DEV)
+    do = torch.randn(S, N, D, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call("hivt_temporal_attn_fwd", _ptr(qkv), S, N, D, H, 0.1, 77, None, _ptr(o), _ptr(lse), s)
+    ref = torch.empty(S, N, 3 * D, device=DEV)
+    got = torch.empty(S, N, 3 * D, device=DEV, dtype=torch.bfloat16)
+    _lib.call("hivt_temporal_attn_bwd", _ptr(do), _ptr(qkv), _ptr(o), _ptr(lse), S, N, D, H, 0.1, 77, None, _ptr(ref), s)
+    _lib.call("hivt_temporal_attn_bwd_half", _ptr(do), _ptr(qkv), _ptr(o), _ptr(lse), S, N, D, H, 0.1, 77, None, _ptr(got),
+              s)
+    assert torch.equal(got, ref.bfloat16())
