@@ -65,6 +65,8 @@ SIGNATURES = {
     "hivt_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hivt_ln_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_int64, c_int32, _P, c_int64, _P, c_int64,
                             _P, _P, _P, c_size_t, _P]),
+    "hivt_ln_bwd_half": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int, c_int64, c_int32, _P, c_int64, _P, c_int64,
+                                 _P, _P, _P, c_size_t, _P]),
     "hivt_linear_bwd_data_half": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int64, c_float, _P,
                                           c_int64, _P, c_int64, c_int32, _P]),
     "hivt_ln_bwd_partial_rows": (c_size_t, [c_int64]),

@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int relu, int64_t M, int N, int vec, float* __restrict__ dz,
                                                      int64_t dz_ld, float* __restrict__ partial /*[grid][2][N]*/,
-                                                     const float* __restrict__ add, int64_t add_ld) {
+                                                     const float* __restrict__ add, int64_t add_ld, int dz_half) {
+  // dz_half: dz points at bfloat16 elements (dz_ld counts them); values are rounded to nearest even
   __shared__ float red[4][2][64 * NPL];
   constexpr int U = 2;  // rows in flight per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -510,7 +511,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         for (int j = 0; j < NPL; ++j)
           if (c0 + j < N) o[j] += add[r * add_ld + c0 + j];
       }
-      if (NPL == 2 && full) {
+      if (dz_half) {
+        unsigned short* hz = reinterpret_cast<unsigned short*>(dz) + r * dz_ld + c0;
+        if (NPL == 2 && full) {
+          *reinterpret_cast<unsigned*>(hz) = (unsigned)to_bf16_bits(o[0]) | ((unsigned)to_bf16_bits(o[NPL - 1]) << 16);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NPL; ++j)
+            if (c0 + j < N) hz[j] = to_bf16_bits(o[j]);
+        }
+      } else if (NPL == 2 && full) {
         *reinterpret_cast<float2*>(dz + r * dz_ld + c0) = make_float2(o[0], o[NPL - 1]);
       } else {
 #pragma unroll
@@ -1248,10 +1258,10 @@ extern "C" size_t hivt_ln_bwd_workspace_bytes(int64_t M, int32_t N) {
   return align_up((size_t)blocks * 2 * (size_t)N * sizeof(float), 256);
 }
 
-extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
-                           const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
-                           int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
-                           size_t workspace_bytes, hivt_stream_t stream) {
+static int ln_bwd_impl(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                       const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                       int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                       size_t workspace_bytes, hivt_stream_t stream, bool dz_half) {
   const char* what = "hivt_ln_bwd";
   HIVT_REQUIRE(M >= 0 && N > 0 && N <= 128, HIVT_ERR_ARG, "%s: N must be in [1,128] (N=%d)", what, N);
   HIVT_REQUIRE((dgamma != nullptr) == (dbeta != nullptr), HIVT_ERR_ARG, "%s: dgamma and dbeta go together", what);
@@ -1271,19 +1281,38 @@ extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64
   const int64_t blocks = ln_bwd_blocks(M);
   float* partial = reinterpret_cast<float*>(workspace);
   auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  // (a bfloat16 dz: a lane's two columns are one 4-byte store, which the requirement below keeps aligned)
+  HIVT_REQUIRE(!dz_half || (al8(dz) && dz_ld % 4 == 0 && N % 4 == 0), HIVT_ERR_ARG,
+               "%s: a bfloat16 dz needs N and dz_ld that are multiples of 4 and rows on 8-byte boundaries", what);
   const int vec = (al8(dy) && al8(z) && al8(dz) && dy_ld % 2 == 0 && z_ld % 2 == 0 && dz_ld % 2 == 0) ? 1 : 0;
   if (N <= 64)
     hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
-                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
+                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld, dz_half ? 1 : 0);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
-                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld);
+                       beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld, dz_half ? 1 : 0);
   HIVT_CHECK_LAUNCH(what);
   if (leave_partials) return HIVT_OK;
   // partial is [blocks][2][N]: one reduction over the 2N columns, first half -> dgamma, second -> dbeta
   launch_reduce_rows(s, partial, (int)blocks, (int64_t)2 * N, 2 * N, dgamma, N, dbeta);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                           const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                           int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, hivt_stream_t stream) {
+  return ln_bwd_impl(dy, dy_ld, z, z_ld, stats, gamma, beta, relu, M, N, add, add_ld, dz, dz_ld, dgamma, dbeta, workspace,
+                     workspace_bytes, stream, false);
+}
+
+extern "C" int hivt_ln_bwd_half(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                                const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                                int64_t add_ld, void* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, hivt_stream_t stream) {
+  return ln_bwd_impl(dy, dy_ld, z, z_ld, stats, gamma, beta, relu, M, N, add, add_ld, reinterpret_cast<float*>(dz), dz_ld,
+                     dgamma, dbeta, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" size_t hivt_ln_bwd_partial_rows(int64_t M) { return M > 0 ? (size_t)ln_bwd_blocks(M) : 0; }

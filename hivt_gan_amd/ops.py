@@ -715,17 +715,18 @@ _deferred_rows: Optional[list] = None  # LayerNorm partial sums waiting for thei
 
 
 def _ln_backward(dy2, z, z_ld, stats, gamma, beta, relu: int, m: int, n: int, add2, dz, stream, leaves: bool):
-    """``hivt_ln_bwd``: fills ``dz`` and returns ``(dgamma, dbeta)``.  With ``leaves`` (gamma and beta are leaves of
+    """``hivt_ln_bwd`` (``hivt_ln_bwd_half`` for a bfloat16 ``dz``): fills ``dz`` and returns ``(dgamma, dbeta)``.  With ``leaves`` (gamma and beta are leaves of
     the graph) inside ``deferred_weight_grads()`` the kernel's partial sums stay in a buffer of their own and one
     grouped reduction at the end of the backward pass fills the two gradients of every LayerNorm."""
     dev = dz.device
     dgamma = torch.empty(n, dtype=torch.float32, device=dev)
     dbeta = torch.empty(n, dtype=torch.float32, device=dev)
     add_ld = add2.stride(0) if add2 is not None else 0
+    name = "hivt_ln_bwd_half" if dz.dtype == torch.bfloat16 else "hivt_ln_bwd"
     if leaves and _deferred is not None and m > 0:
         rows = _lib.query("hivt_ln_bwd_partial_rows", m)
         part = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", m, n) // 4, dtype=torch.float32, device=dev)
-        _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
+        _lib.call(name, _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
                   _p(add2), add_ld, _p(dz), dz.stride(0), None, None, _p(part), part.numel() * 4, stream)
         if not _deferred and not _deferred_rows:
             torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
@@ -733,7 +734,7 @@ def _ln_backward(dy2, z, z_ld, stats, gamma, beta, relu: int, m: int, n: int, ad
                                part))
         return dgamma, dbeta
     ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
-    _lib.call("hivt_ln_bwd", _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
+    _lib.call(name, _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
               _p(add2), add_ld, _p(dz), dz.stride(0), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), stream)
     return dgamma, dbeta
 
@@ -800,13 +801,18 @@ class _FusedLinear(torch.autograd.Function):
         dy2 = _rows2(dy)
         s = _stream(x2)
         dgamma = dbeta = None
+        # a dz made here that only the two products read (no gradient of `add` to take from it): bfloat16 in
+        # memory while those products round it to bfloat16 anyway
+        half = (_half_gradients() and n % 4 == 0 and k % 4 == 0 and not (has_add and ctx.needs_input_grad[3])
+                and x2.stride(0) % 4 == 0 and w2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0)
         if ln:
-            dz = torch.empty(m, n, dtype=torch.float32, device=dev)
+            dz = torch.empty(m, n, dtype=torch.bfloat16 if half else torch.float32, device=dev)
             dgamma, dbeta = _ln_backward(dy2, z, n, stats, gamma, beta, int(relu), m, n, None, dz, s, ctx.norm_leaves)
         elif dropout_p > 0.0:
-            dz = torch.empty(m, n, dtype=torch.float32, device=dev)
-            _lib.call("hivt_dropout_bwd", _p(dy2), dy2.stride(0), _p(y_relu), n, int(relu), dropout_p, seed,
-                      _p(seed_dev), m, n, _p(dz), n, s)
+            half = half and dy2.stride(0) % 4 == 0 and dy2.data_ptr() % 16 == 0
+            dz = torch.empty(m, n, dtype=torch.bfloat16 if half else torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd_half" if half else "hivt_dropout_bwd", _p(dy2), dy2.stride(0), _p(y_relu), n,
+                      int(relu), dropout_p, seed, _p(seed_dev), m, n, _p(dz), n, s)
         elif relu:
             dz = torch.ops.aten.threshold_backward(dy2, y_relu, 0.0)  # dy where y > 0, one launch
         else:
@@ -814,8 +820,12 @@ class _FusedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(m, k, dtype=torch.float32, device=dev)
-            _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, None, 0,
-                      _p(dx), k, s)
+            if dz.dtype == torch.bfloat16:
+                _lib.call("hivt_linear_bwd_data_half", _p(dz), n, _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, None, 0,
+                          _p(dx), k, HALF_DY, s)
+            else:
+                _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, None,
+                          0, _p(dx), k, s)
             dx = dx.view(*lead, k)
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = _weight_grad(dz, dz.stride(0), x2, x2.stride(0), m, n, k, dev, bias=has_bias,

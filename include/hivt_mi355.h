@@ -337,6 +337,12 @@ int hivt_ln_bwd(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, co
                 const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
                 int64_t add_ld, float* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
                 size_t workspace_bytes, hivt_stream_t stream);
+/* The same with dz stored as bfloat16 [M,N] (nearest even, after `add`; dz_ld in elements; N and dz_ld multiples
+ * of 4): for a dz that only bf16 products read, see below. */
+int hivt_ln_bwd_half(const float* dy, int64_t dy_ld, const float* z, int64_t z_ld, const float* stats,
+                     const float* gamma, const float* beta, int relu, int64_t M, int32_t N, const float* add,
+                     int64_t add_ld, void* dz, int64_t dz_ld, float* dgamma, float* dbeta, void* workspace,
+                     size_t workspace_bytes, hivt_stream_t stream);
 
 /* Gradients that only bf16 products consume may live in memory as bfloat16: those products round their operands to
  * bfloat16 when they stage them, so storing the rounded values changes no product and halves the bytes.  Valid

@@ -361,3 +361,52 @@ def test_temporal_attention_backward_writes_bfloat16():
     _lib.call("hivt_temporal_attn_bwd_half", _ptr(do), _ptr(qkv), _ptr(o), _ptr(lse), S, N, D, H, 0.1, 77, None, _ptr(got),
               s)
     assert torch.equal(got, ref.bfloat16())
+
+
+@pytest.mark.parametrize("M,K,N,ln,relu,p,with_add", [(5000, 128, 128, True, True, 0.0, False),
+                                                     (3001, 256, 128, True, False, 0.0, False),
+                                                     (777, 64, 64, True, True, 0.0, False),
+                                                     (5000, 128, 128, False, True, 0.1, False),
+                                                     (5000, 128, 128, True, True, 0.0, True)])
+def test_fused_linear_with_bfloat16_gradient_matches_the_fp32_memory_path(M, K, N, ln, relu, p, with_add):
+    """The gradient behind a LayerNorm / dropout epilogue feeds the layer's two gradient products only, so it is
+    kept as bfloat16; with an `add` operand that needs it as its own gradient it stays fp32 (nothing changes)."""
+    torch.manual_seed(M)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    norm = torch.nn.LayerNorm(N).to(DEV) if ln else None
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    add = torch.randn(M, N, device=DEV, requires_grad=True) if with_add else None
+    gy = torch.randn(M, N, device=DEV)
+    params = [x, lin.weight, lin.bias] + ([norm.weight, norm.bias] if ln else []) + ([add] if with_add else [])
+
+    def grads():
+        torch.manual_seed(13)
+        for q in params:
+            q.grad = None
+        ops.fused_linear(x, lin.weight, lin.bias, add=add, layer_norm=norm, relu=relu, dropout_p=p,
+                         training=True).backward(gy)
+        return [q.grad.clone() for q in params]
+
+    _half_vs_full(grads, loose=() if with_add else (2,))
+
+
+@pytest.mark.parametrize("M,N,relu,with_add", [(5000, 128, True, False), (333, 64, False, True), (70_001, 128, False, False),
+                                               (3, 4, True, False)])
+def test_layer_norm_backward_writes_bfloat16(M, N, relu, with_add):
+    torch.manual_seed(M + N)
+    z = torch.randn(M, N, device=DEV) * 2 + 0.5
+    stats = torch.stack([z.mean(1), (z.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    gamma, beta = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    dy = torch.randn(M, N, device=DEV)
+    add = torch.randn(M, N, device=DEV) if with_add else None
+    s = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", M, N), dtype=torch.uint8, device=DEV)
+    outs = []
+    for name, dt in (("hivt_ln_bwd", torch.float32), ("hivt_ln_bwd_half", torch.bfloat16)):
+        dz = torch.empty(M, N, device=DEV, dtype=dt)
+        dg, db = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+        _lib.call(name, _ptr(dy), N, _ptr(z), N, _ptr(stats), _ptr(gamma), _ptr(beta), int(relu), M, N, _ptr(add), N,
+                  _ptr(dz), N, _ptr(dg), _ptr(db), _ptr(ws), ws.numel(), s)
+        outs.append((dz, dg, db))
+    assert torch.equal(outs[1][0], outs[0][0].bfloat16())
+    assert torch.equal(outs[1][1], outs[0][1]) and torch.equal(outs[1][2], outs[0][2])
