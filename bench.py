@@ -48,10 +48,12 @@ def model_config(embed_dim: int, local_radius: float = 50.0):
                 lambda_adv=0.1, lambda_r1=1.0, critic_steps=1, short_horizon=10, mid_horizon=20, critic_lr=1e-4)
 
 
-def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool, n_live: int = None) -> float:
+def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool, n_live: int = None,
+                   grad_bytes: int = 4) -> float:
     """Algorithmic HBM bytes of one launch (fp32 rows, int32 CSR).  ``n_live`` = target rows with at
     least one edge: a row without edges needs neither its query nor (backward) its output / output
-    gradient, and the kernels skip those loads, so they are not credited."""
+    gradient, and the kernels skip those loads, so they are not credited.  ``grad_bytes``: bytes per element
+    of the dK / dV rows a backward launch writes (2 where they are kept as bfloat16)."""
     s = 4
     n_live = n if n_live is None else n_live
     if kind == "fwd":
@@ -61,7 +63,7 @@ def seg_attn_bytes(kind: str, n: int, e: int, d: int, h: int, node_terms: bool, 
             b += n * 2 * d * s + e * 4
     else:
         # K, V read, dK, dV written; rowptr; q, out, d_out (+ max / denominator) of live rows; dq of every row
-        b = e * 4 * d * s + n * 4 + n_live * (3 * d * s + h * 8) + n * d * s
+        b = e * 2 * d * (s + grad_bytes) + n * 4 + n_live * (3 * d * s + h * 8) + n * d * s
         if node_terms:
             b += n * 2 * d * s + e * 4
     return float(b)
@@ -349,18 +351,19 @@ def main():
 
     if rank == 0:
         groups = {}
-        for kind, tag, n, rowptr, d, h, node_terms, ev0, ev1 in records:
+        for kind, tag, n, rowptr, d, h, node_terms, ev0, ev1, grad_bytes in records:
             rp = rowptr.cpu()
-            groups.setdefault((kind, tag, node_terms, d, h), []).append(
+            groups.setdefault((kind, tag, node_terms, d, h, grad_bytes), []).append(
                 (n, int(rp[n]), ev0.elapsed_time(ev1) * 1e-3, int((rp[1:] > rp[:-1]).sum())))
         roofline, extra = None, []
         traffic = measured_traffic(args.embed_dim, args.scenes)
-        for (kind, tag, node_terms, d, h), rows in groups.items():
-            by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms, live) for n, e, _, live in rows) / len(rows)
+        for (kind, tag, node_terms, d, h, grad_bytes), rows in groups.items():
+            by = sum(seg_attn_bytes(kind, n, e, d, h, node_terms, live, grad_bytes) for n, e, _, live in rows) / len(rows)
             tm = sum(r[2] for r in rows) / len(rows)
             entry = {"kernel": f"seg_attn_{kind}_kernel", "caller": tag, "bound": "hbm", "achieved": by / tm / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / tm / 1e9 / HBM_PEAK_GBS, "traffic": traffic.get(f"{kind}/{tag}"),
                      "bytes_per_launch": by, "avg_launch_us": tm * 1e6, "launches": len(rows),
+                     "grad_row_dtype": "bf16" if grad_bytes == 2 else "f32",
                      "edges_per_launch": sum(r[1] for r in rows) / len(rows),
                      "rows_per_launch": sum(r[0] for r in rows) / len(rows),
                      "rows_with_edges_per_launch": sum(r[3] for r in rows) / len(rows)}

@@ -53,6 +53,7 @@ struct SegAttnArgs {
   float* dk;
   float* dv;
   int64_t dkv_stride;
+  int32_t dkv_half;  // dk / dv point at bfloat16 elements (dkv_stride counts them); values rounded to nearest even
   // optional: events that receive the kernel's own start / stop time stamps
   hipEvent_t ev_start;
   hipEvent_t ev_stop;
@@ -228,7 +229,14 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   }
 }
 
-template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL>
+// four values as bfloat16 (nearest even) in 8 bytes
+__device__ __forceinline__ uint2 pack_bf16x4(float x, float y, float z, float w) {
+  auto bits = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
+  return make_uint2(bits(x) | (bits(y) << 16), bits(z) | (bits(w) << 16));
+}
+
+// HALF: dk / dv are bfloat16 rows (a compile-time switch: the fp32 kernels keep their code as it was)
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL, bool HALF = false>
 __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
   constexpr bool GLOBAL = KIND == kRowsNodeTerms;
   constexpr bool INTERLEAVED = KIND == kRowsInterleaved;
@@ -305,10 +313,18 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
         const float am = alpha * ms;
         const float ds = alpha * (dav * ms - delta);
         const int64_t er = INTERLEAVED ? (e - beg) * a.row_interleave + nc : e;
-        *reinterpret_cast<float4*>(a.dv + er * a.dkv_stride + 4 * c) =
-            make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
-        *reinterpret_cast<float4*>(a.dk + er * a.dkv_stride + 4 * c) =
-            make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+        if constexpr (HALF) {
+          const int64_t at = er * a.dkv_stride + 4 * c;
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dv) + at) =
+              pack_bf16x4(am * go.x, am * go.y, am * go.z, am * go.w);
+          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dk) + at) =
+              pack_bf16x4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+        } else {
+          *reinterpret_cast<float4*>(a.dv + er * a.dkv_stride + 4 * c) =
+              make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
+          *reinterpret_cast<float4*>(a.dk + er * a.dkv_stride + 4 * c) =
+              make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+        }
         fma4(dq, ds, kk[u]);
       }
     }
@@ -336,15 +352,20 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
 // that everything upstream of the projection sees exact zeros for the padding.
 __global__ __launch_bounds__(256) void zero_tail_kernel(const int32_t* __restrict__ rowptr, int32_t N, int64_t E_cap,
                                                         int32_t D, float* __restrict__ dk, float* __restrict__ dv,
-                                                        int64_t stride) {
+                                                        int64_t stride, int half) {
   const int64_t live = rowptr[N];
   const int64_t quads = D / 4;
   const int64_t total = (E_cap - live) * quads;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = live + i / quads;
     const int c = (int)(i % quads) * 4;
-    *reinterpret_cast<float4*>(dk + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(dv + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (half) {  // bfloat16 rows: four zeros are 8 bytes
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dk) + e * stride + c) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dv) + e * stride + c) = make_uint2(0u, 0u);
+    } else {
+      *reinterpret_cast<float4*>(dk + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dv + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -358,7 +379,13 @@ int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
     SegAttnArgs k = a;
     k.ev_start = nullptr;
     k.ev_stop = nullptr;
-    if (backward)
+    if (backward && a.dkv_half) {
+      if constexpr (GLOBAL == kRowsPlain)
+        hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL, true>), dim3(grid), dim3(256), 0,
+                              stream, a.ev_start, a.ev_stop, 0, k);
+      else
+        return -1;
+    } else if (backward)
       hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream,
                             a.ev_start, a.ev_stop, 0, k);
     else
@@ -366,7 +393,14 @@ int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
                             a.ev_start, a.ev_stop, 0, k);
     return 0;
   }
-  if (backward)
+  if (backward && a.dkv_half) {
+    // bfloat16 dk / dv: built for plain rows (no node terms, not interleaved)
+    if constexpr (GLOBAL == kRowsPlain)
+      hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL, true>), dim3(grid), dim3(256), 0, stream,
+                         a);
+    else
+      return -1;
+  } else if (backward)
     hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
@@ -568,13 +602,18 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
   a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = const_cast<float*>(out); a.m = const_cast<float*>(m); a.den = const_cast<float*>(den);
   a.d_out = d_out; a.dq = dq; a.dk = dk; a.dv = dv; a.dkv_stride = dkv_stride;
+  a.dkv_half = (dtype & HIVT_DKV_BF16) ? 1 : 0;
+  HIVT_REQUIRE(!a.dkv_half || (!global && !(dtype & HIVT_ROWS_INTERLEAVED)), HIVT_ERR_UNSUPPORTED,
+               "%s: bfloat16 dk / dv are built for plain rows only (no node terms, not interleaved)", what);
+  HIVT_REQUIRE(!a.dkv_half || E == 0 || ((reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 7) == 0,
+               HIVT_ERR_ARG, "%s: bfloat16 dk / dv rows must start on 8-byte boundaries", what);
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, true, E, global, dtype, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d (launch-shape hint 0x%x)", what, D, H, dtype >> 8);
   HIVT_CHECK_LAUNCH(what);
   if (zero_tail && E > 0) {
     hipLaunchKernelGGL(zero_tail_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, rowptr, N, E, D, dk, dv,
-                       dkv_stride);
+                       dkv_stride, a.dkv_half);
     HIVT_CHECK_LAUNCH(what);
   }
   return HIVT_OK;

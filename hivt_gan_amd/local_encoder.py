@@ -224,11 +224,17 @@ class _EdgeAttentionBase(nn.Module):
         """``[residual +]`` message (Q.K, segment softmax, weighting) + aggregate + update + out_proj +
         dropout for per-edge embeddings already in CSR order (``local_encoder.py:174-188,197-199`` /
         ``:364-379,391-394``)."""
-        kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
         q = _linear(center, self.lin_q)
         # `rowptr`: the edge set's row pointer re-indexed to packed target rows (`center` then holds those rows)
-        agg = ops.seg_attn(q, kv, edges.rowptr if rowptr is None else rowptr, self.num_heads, self.attn_drop.p,
-                           self.training, tag=type(self).__name__, padded=edges.count is not None)
+        rowptr = edges.rowptr if rowptr is None else rowptr
+        if edge_embed.is_cuda and edge_embed.dtype == torch.float32 and edge_embed.dim() == 2:
+            # key | value projection and attention as one node: their shared gradient stays inside it
+            agg = ops.edge_attention(q, edge_embed, self.lin_k, self.lin_v, rowptr, self.num_heads, self.attn_drop.p,
+                                     self.training, tag=type(self).__name__, padded=edges.count is not None)
+        else:
+            kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
+            agg = ops.seg_attn(q, kv, rowptr, self.num_heads, self.attn_drop.p, self.training,
+                               tag=type(self).__name__, padded=edges.count is not None)
         if residual is not None:
             return ops.gated_update_tail(agg, center, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
                                          self.proj_drop.p, self.proj_drop.training)

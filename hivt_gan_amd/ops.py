@@ -302,7 +302,8 @@ def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, sr
 SEG_ATTN_TIMING = None
 
 
-def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args):
+def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args, grad_bytes=4):
+    """``grad_bytes``: bytes per element of the dk / dv rows a backward launch writes (2 for bfloat16 rows)."""
     rec = SEG_ATTN_TIMING
     if rec is None:
         _lib.call(name, *args)
@@ -313,7 +314,7 @@ def _timed_call(kind, tag, n, live, d_model, heads, node_terms, dev, name, *args
     ev0.record(stream)  # creates the underlying events; the timed launch re-records them with the
     ev1.record(stream)  # kernel's own start / stop time stamps
     _lib.call(name + "_timed", *args, int(ev0.cuda_event), int(ev1.cuda_event))
-    rec.append((kind, tag, n, live, d_model, heads, node_terms, ev0, ev1))
+    rec.append((kind, tag, n, live, d_model, heads, node_terms, ev0, ev1, grad_bytes))
 
 
 # Dropout seeds.  Every call draws a host-side seed (CPU generator: no device sync, reproducible
@@ -401,15 +402,22 @@ class _SegAttn(torch.autograd.Function):
         e = kv.shape[0]
         d_out = d_out.contiguous()
         dq = torch.empty_like(q)
-        dkv = torch.empty(e, 2 * d_model, dtype=torch.float32, device=q.device)
-        fb = 4 * d_model
+        # (set by a caller that consumes the key | value gradient itself, see _EdgeAttention)
+        half = bool(getattr(ctx, "dkv_half", False))
+        if half and (kv_node is not None or interleaved):
+            raise RuntimeError("bfloat16 key | value gradients: plain rows only")
+        dkv = torch.empty(e, 2 * d_model, dtype=torch.bfloat16 if half else torch.float32, device=q.device)
+        fb_kv = 4 * d_model
+        fb = 2 * d_model if half else 4 * d_model
+        layout = (ROWS_INTERLEAVED if interleaved else 0) | (DKV_BF16 if half else 0)
         _timed_call("bwd", tag, n, rowptr, d_model, num_heads, kv_node is not None, q.device,
-                    "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
-                  _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
-                  kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                  _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
-                  _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, ROWS_INTERLEAVED if interleaved else 0,
-                  _stream(q))
+                    "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb_kv),
+                    kv.stride(0) if e > 0 else 2 * d_model,
+                    _p(kv_node), _p(kv_node, fb_kv) if kv_node is not None else None,
+                    kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
+                    _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
+                    _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, layout, _stream(q),
+                    grad_bytes=2 if half else 4)
         dkv_node = None
         if kv_node is not None and ctx.needs_input_grad[2]:
             ns = kv_node.shape[0]
@@ -420,6 +428,7 @@ class _SegAttn(torch.autograd.Function):
 
 
 ROWS_INTERLEAVED = 1 << 16  # layout flag in the dtype argument of hivt_seg_attn_fwd / _bwd
+DKV_BF16 = 1 << 17          # hivt_seg_attn_bwd: dk / dv are bfloat16 rows
 
 
 def seg_attn_supported(d_model: int, num_heads: int) -> bool:
@@ -917,13 +926,20 @@ class _PairLinear(torch.autograd.Function):
         m, k = x2.shape
         n = w.shape[0]
         dev = x2.device
-        dy2 = _rows2(dy)
+        half = dy.dtype == torch.bfloat16  # handed over by _EdgeAttention, never by autograd
+        if half and (dy.shape != (m, n) or not dy.is_contiguous() or (table_rows and ctx.needs_input_grad[5])):
+            raise RuntimeError("a bfloat16 gradient must be a contiguous [rows, n_a + n_b] tensor of a layer without table rows")
+        dy2 = dy if half else _rows2(dy)
         s = _stream(x2)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(m, k, dtype=torch.float32, device=dev)
-            _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0, None, 0,
-                      _p(dx), k, s)
+            if half:
+                _lib.call("hivt_linear_bwd_data_half", _p(dy2), n, _p(w), w.stride(0), m, n, k, None, 0, 1.0, None, 0,
+                          _p(dx), k, HALF_DY, s)
+            else:
+                _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0, None,
+                          0, _p(dx), k, s)
             dx = dx.view(*lead, k)
         dw, db = _weight_grad(dy2, dy2.stride(0), x2, x2.stride(0), m, n, k, dev, leaves=ctx.param_leaves)
         d_table = None
@@ -948,6 +964,69 @@ def pair_linear(x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear, table: 
     if table.requires_grad and (rowptr_by_index is None or perm_by_index is None):
         raise ValueError("gradient of the table rows needs the grouping of the rows by index")
     return _PairLinear.apply(x, a.weight, a.bias, b.weight, b.bias, table, index, rowptr_by_index, perm_by_index)
+
+
+class _StandInContext:
+    """What a Function's forward / backward use of their context, for a node that runs another node's two halves
+    itself: tensors are kept by the outer node's context and handed back here."""
+
+    def __init__(self, needs_input_grad=()):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _EdgeAttention(torch.autograd.Function):
+    """``seg_attn(q, [a(x) | b(x)], rowptr)``: the key | value projection of the edge rows and the attention over
+    the CSR rows (``models/local_encoder.py:166-181, 356-371``) as ONE node.  Same launches as ``pair_linear``
+    followed by ``seg_attn``; the gradient of the projected rows stays inside the node, where its only readers
+    are the projection's two gradient products -- while those run in bf16 mode it is written and read as
+    bfloat16 (between two nodes autograd would widen it to the forward tensor's dtype)."""
+
+    @staticmethod
+    def forward(ctx, q, x, w_a, b_a, w_b, b_b, rowptr, num_heads, dropout_p, seed, tag, padded):
+        proj, attn = _StandInContext(), _StandInContext()
+        kv = _PairLinear.forward(proj, x, w_a, b_a, w_b, b_b)
+        out = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, dropout_p, seed, tag, padded)
+        ctx.save_for_backward(*proj.saved_tensors, *attn.saved_tensors)
+        ctx.split = len(proj.saved_tensors)
+        ctx.stages = (proj.cfg, proj.param_leaves, attn.cfg)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        saved = ctx.saved_tensors
+        proj_cfg, param_leaves, attn_cfg = ctx.stages
+        need = ctx.needs_input_grad
+        attn = _StandInContext((need[0], True, False) + (False,) * 10)
+        attn.saved_tensors, attn.cfg = saved[ctx.split:], attn_cfg
+        proj = _StandInContext((need[1],) + (True,) * 4 + (False,) * 4)
+        proj.saved_tensors, proj.cfg, proj.param_leaves = saved[:ctx.split], proj_cfg, param_leaves
+        x2, w = saved[0], saved[1]
+        k, n = x2.shape[1], w.shape[0]
+        attn.dkv_half = (_half_gradients() and k % 4 == 0 and n % 8 == 0 and x2.stride(0) % 4 == 0
+                         and w.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+        grads = _SegAttn.backward(attn, d_out)
+        dq, dkv = grads[0], grads[1]
+        dx, dw_a, db_a, dw_b, db_b = _PairLinear.backward(proj, dkv)[:5]
+        return dq, dx, dw_a, db_a, dw_b, db_b, None, None, None, None, None, None
+
+
+def edge_attention(q: torch.Tensor, x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear, rowptr: torch.Tensor,
+                   num_heads: int, dropout_p: float = 0.0, training: bool = False, tag: str = "",
+                   padded: bool = False) -> torch.Tensor:
+    """``seg_attn(q, pair_linear(x, a, b), rowptr, ...)`` as one autograd node: ``x`` [E, K] are the edge rows in CSR
+    order, ``a`` / ``b`` the key and value projections, ``q`` [N, D] the queries.  Results equal the two calls' bit
+    for bit in fp32 mode; in "bf16" mode the projected rows' gradient is kept as bfloat16 (the gradient products
+    see the same values, the two bias gradients become sums of rounded values)."""
+    if x.dim() != 2:
+        raise ValueError(f"edge rows must be [E, K], got {tuple(x.shape)}")
+    p = float(dropout_p) if training else 0.0
+    return _EdgeAttention.apply(q, x, a.weight, a.bias, b.weight, b.bias, rowptr, int(num_heads), p,
+                                _fresh_seed() if p > 0.0 else 0, tag, bool(padded))
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -165,6 +165,11 @@ int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angl
  * encoder's final layer, which is all the encoder's caller reads of it (models/local_encoder.py:241).  No node
  * terms and no padded tail in this layout. */
 #define HIVT_ROWS_INTERLEAVED (1 << 16)
+/* Flag of hivt_seg_attn_bwd's `dtype` argument (bit 17): dk and dv point at bfloat16 rows (dkv_stride counts
+ * bfloat16 elements, rows on 8-byte boundaries); the gradients are rounded to nearest even where they are stored.
+ * For key / value rows that a projection made whose two gradient products run in bf16 mode: those products would
+ * round the rows anyway (see hivt_linear_bwd_data_half), and the kernel writes half the bytes. */
+#define HIVT_DKV_BF16 (1 << 17)
 
 /* out[n,h,:] = sum_{e in row n} drop(softmax_e(q[n,h,:] . key_e[h,:] / sqrt(D/H))) * val_e[h,:]
  * with key_e = k[e] (+ k_node[src[e]] when k_node != NULL), val_e likewise; softmax is

@@ -410,3 +410,63 @@ def test_layer_norm_backward_writes_bfloat16(M, N, relu, with_add):
         outs.append((dz, dg, db))
     assert torch.equal(outs[1][0], outs[0][0].bfloat16())
     assert torch.equal(outs[1][1], outs[0][1]) and torch.equal(outs[1][2], outs[0][2])
+
+
+def _edge_problem(n_rows, max_deg, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (n_rows,), generator=g)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]).to(torch.int32).to(DEV)
+    e = int(deg.sum())
+    return rowptr, e
+
+
+@pytest.mark.parametrize("n_rows,max_deg,D,H,p,pad", [(3000, 3, 128, 8, 0.1, 0), (500, 90, 128, 8, 0.0, 37),
+                                                      (2000, 30, 64, 8, 0.1, 0), (64, 5, 128, 8, 0.0, 0)])
+def test_edge_attention_node_equals_projection_then_attention(n_rows, max_deg, D, H, p, pad):
+    """The one-node form launches the same kernels as pair_linear followed by seg_attn: bit-identical output and
+    gradients in fp32 mode; in "bf16" mode its bfloat16 key | value gradient changes only the two bias gradients
+    beyond fp32 rounding (they become sums of rounded values)."""
+    rowptr, e = _edge_problem(n_rows, max_deg, D, seed=n_rows)
+    torch.manual_seed(n_rows + 1)
+    lin_k, lin_v = torch.nn.Linear(D, D).to(DEV), torch.nn.Linear(D, D).to(DEV)
+    x = torch.randn(e + pad, D, device=DEV, requires_grad=True)
+    q = torch.randn(n_rows, D, device=DEV, requires_grad=True)
+    g_out = torch.randn(n_rows, D, device=DEV)
+    params = [q, x, lin_k.weight, lin_k.bias, lin_v.weight, lin_v.bias]
+
+    def run(one_node):
+        torch.manual_seed(21)
+        for t in params:
+            t.grad = None
+        if one_node:
+            out = ops.edge_attention(q, x, lin_k, lin_v, rowptr, H, p, True, padded=pad > 0)
+        else:
+            out = ops.seg_attn(q, ops.pair_linear(x, lin_k, lin_v), rowptr, H, p, True, padded=pad > 0)
+        out.backward(g_out)
+        return [out.detach().clone()] + [t.grad.clone() for t in params]
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+    prev = ops.set_matmul_precision("bf16")
+    try:
+        half, full = run(True), run(False)
+    finally:
+        ops.set_matmul_precision(prev)
+    # the bias gradients are column sums of the key | value gradient: with rounded terms a sum moves by at most
+    # 2^-9 of the sum of the terms' magnitudes (the key bias gradient itself is zero up to cancellation noise:
+    # a shift of every key leaves the softmax as it is)
+    torch.manual_seed(21)
+    kv = ops.pair_linear(x, lin_k, lin_v).detach().requires_grad_(True)
+    ops.seg_attn(q, kv, rowptr, H, p, True, padded=pad > 0).backward(g_out)
+    bound = kv.grad.abs().sum(0) * 2.0 ** -9 + 1e-6
+    # (the kernel that stores bfloat16 rows is a build of its own: the compiler fuses some multiply-adds of the
+    # query gradient differently, so the other gradients agree to fp32 rounding instead of bit for bit)
+    for i, (a, b) in enumerate(zip(half, full)):
+        if i in (4, 6):
+            assert bool(((a - b).abs() <= (bound[:D] if i == 4 else bound[D:])).all()), i
+        elif i in (0, 1):
+            assert rel(a, b) < 1e-5, i
+        else:  # products of the rounded rows: a last-bit difference before the rounding moves a few of them by
+            assert rel(a, b) < 1e-3, i  # one bfloat16 step (2^-8 of one term among hundreds)
+    if pad:
+        assert float(half[2][e:].abs().max()) == 0.0  # rows of the padding receive exact zeros
