@@ -329,6 +329,8 @@ __global__ void csr_place_kernel(const int32_t* __restrict__ key, int64_t E, con
   }
 }
 
+constexpr int kSortChunks = 8;  // rows of up to kSortChunks * 64 ids are ranked out of registers
+
 // One wave per row: rank every edge id among the ids of its row (ids are distinct) and write it to
 // its rank, giving ascending original positions = the stable order.
 __global__ __launch_bounds__(256) void csr_row_sort_kernel(const int32_t* __restrict__ rowptr,
@@ -344,6 +346,28 @@ __global__ __launch_bounds__(256) void csr_row_sort_kernel(const int32_t* __rest
     int rank = 0;
     for (int j = 0; j < len; ++j) rank += (__shfl(mine, j, 64) < mine) ? 1 : 0;
     if (lane < len) perm[beg + rank] = mine;
+  } else if (len <= kSortChunks * kWave) {
+    // up to eight ids per lane, held in registers: every id of the row is broadcast once and compared with all of
+    // them (len broadcasts instead of len memory reads per id)
+    int v[kSortChunks], rank[kSortChunks];
+#pragma unroll
+    for (int c = 0; c < kSortChunks; ++c) {
+      const int i = c * kWave + lane;
+      v[c] = i < len ? tmp[beg + i] : 0x7fffffff;
+      rank[c] = 0;
+    }
+#pragma unroll
+    for (int cs = 0; cs < kSortChunks; ++cs) {
+      const int n = min(kWave, len - cs * kWave);  // ids in chunk cs (uniform over the wave; <= 0: none)
+      for (int j = 0; j < n; ++j) {
+        const int s = __shfl(v[cs], j, 64);
+#pragma unroll
+        for (int c = 0; c < kSortChunks; ++c) rank[c] += (s < v[c]) ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kSortChunks; ++c)
+      if (c * kWave + lane < len) perm[beg + rank[c]] = v[c];
   } else {
     for (int i = lane; i < len; i += kWave) {
       const int mine = tmp[beg + i];

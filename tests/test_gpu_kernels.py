@@ -100,7 +100,8 @@ def test_empty_edge_lists():
     assert rowptr.cpu().tolist() == [0] * 8 and perm.numel() == 0
 
 
-@pytest.mark.parametrize("e,rows", [(1, 1), (1000, 37), (50_000, 640), (200_000, 50), (30_000, 20_000)])
+@pytest.mark.parametrize("e,rows", [(1, 1), (1000, 37), (50_000, 640), (200_000, 50), (30_000, 20_000), (40_000, 100),
+                                    (60_000, 120), (141_000, 2600)])
 def test_csr_is_stable_sort(e, rows):
     gen = torch.Generator().manual_seed(e + rows)
     key = torch.randint(0, rows, (e,), generator=gen, dtype=torch.int32)
