@@ -1005,3 +1005,23 @@ def test_pair_linear_adds_table_rows(m, rows, D):
         ops.pair_linear(xg, ag, bg, table=tg, index=idx_g)  # a table that needs a gradient needs the grouping
     with pytest.raises(ValueError):
         ops.pair_linear(xg, ag, bg, table=tg.detach(), index=idx_g.long())
+
+
+@pytest.mark.parametrize("M,N,R", [(70_001, 128, 32), (5000, 128, 20), (333, 64, 3), (1, 128, 16), (4097, 60, 7),
+                                   (141_000, 128, 12)])
+def test_rowsum_by_code_matches_index_add_and_repeats(M, N, R):
+    """Per-code sums of rows (gradient of a small table added per row): against a float64 index_add, with codes
+    outside the table ignored, on a strided input, and bit-identical from call to call (fixed summation order)."""
+    gen = torch.Generator().manual_seed(M + N + R)
+    wide = torch.randn(M, N + 4, generator=gen).to(DEV)
+    x = wide[:, :N]  # row stride N + 4
+    idx = torch.randint(0, R, (M,), generator=gen).to(torch.int32)
+    if M > 10:
+        idx[3], idx[7] = R + 5, -2  # outside the table: contribute nothing
+    idx = idx.to(DEV)
+    got = ops._rowsum_by_code(x, idx, R)
+    keep = (idx >= 0) & (idx < R)
+    want = torch.zeros(R, N, dtype=torch.float64, device=DEV).index_add_(0, idx[keep].long(), x[keep].double())
+    scale = float(x.abs().sum(0).max()) + 1e-6
+    assert float((got.double() - want).abs().max()) < 2e-6 * scale
+    assert torch.equal(ops._rowsum_by_code(x, idx, R), got)
