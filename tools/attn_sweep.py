@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--no-node-terms", action="store_true",
                     help="time the interaction set without the per-source node rows (what the in-kernel gathers cost)")
     ap.add_argument("--only", default=None, help="time only this edge set (agent-agent, lane-actor, interaction)")
+    ap.add_argument("--half-grads", action="store_true",
+                    help="backward writes dK | dV as bfloat16 rows (sets without node terms only)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     D, H = 128, 8
@@ -65,9 +67,12 @@ def main():
         m = torch.empty(n, H, device=dev)
         den = torch.empty(n, H, device=dev)
         dq = torch.empty(n, D, device=dev)
-        dkv = torch.empty(e, 2 * D, device=dev)
+        half = args.half_grads and not node_terms
+        dkv = torch.empty(e, 2 * D, device=dev, dtype=torch.bfloat16 if half else torch.float32)
         src = es.src if node_terms else None
         fb = 4 * D
+        gfb = 2 * D if half else 4 * D      # byte offset of dV inside a dK | dV row
+        gflag = ops.DKV_BF16 if half else 0
         results = {"fwd": {}, "bwd": {}}
 
         def fwd(hint_bits, ev0, ev1, kv):
@@ -82,8 +87,8 @@ def main():
                       kv_node.data_ptr() if node_terms else None, kv_node.data_ptr() + fb if node_terms else None,
                       2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(),
                       out.data_ptr(), m.data_ptr(), den.data_ptr(), n, e, D, H, 0.1, 1234, None, dq.data_ptr(),
-                      dkv.data_ptr(), dkv.data_ptr() + fb, 2 * D, 0, hint_bits, stream.cuda_stream, int(ev0.cuda_event),
-                      int(ev1.cuda_event))
+                      dkv.data_ptr(), dkv.data_ptr() + gfb, 2 * D, 0, hint_bits | gflag, stream.cuda_stream,
+                      int(ev0.cuda_event), int(ev1.cuda_event))
 
         with torch.no_grad():
             kv_fixed = ops.pair_linear(embed, lin_k, lin_v)
@@ -108,7 +113,7 @@ def main():
         print(f"== {tag}: {n} rows ({live} with edges), {e} edges, avg {e / max(n, 1):.1f} per row; "
               f"non-empty row length p10/p50/p90/p99/max {[int(v) for v in qs]}")
         for kind in ("fwd", "bwd"):
-            by = bench.seg_attn_bytes(kind, n, e, D, H, node_terms, live)
+            by = bench.seg_attn_bytes(kind, n, e, D, H, node_terms, live, 2 if (half and kind == "bwd") else 4)
             line = []
             for shape, evs in results[kind].items():
                 us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in evs[2:])
