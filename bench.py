@@ -210,6 +210,10 @@ def main():
                     help="dense-scene stress shape instead of the headline workload: 200 agents and 1000 lane "
                          "segments per scene, 150 m radius, every step valid (use with --scenes 2..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity-slack", type=float, default=1.0,
+                    help="head room of the recorded step's fixed edge / node capacities over the largest batch of the "
+                         "pool (1.0: the pool is all the data this run sees; the library's default for a data stream "
+                         "is 1.1 for edges, 1.05 for nodes -- padded rows are computed like real ones)")
     ap.add_argument("--matmul", choices=("fp32", "bf16"), default="bf16",
                     help="operand precision of the dense products: bf16 operands with fp32 accumulation (the named "
                          "workload's precision, results within 2e-2) or fp32 throughout (within 1e-5)")
@@ -254,9 +258,10 @@ def main():
     for i in range(args.pool):
         b = hv.make_batch(args.scenes, first_index=(rank * args.pool + i) * args.scenes, **scene_kwargs).to(dev)
         pool.append((b, b["y"]))
-    # capacities of the filtered edge lists, measured once over the pool with 10 % head room: with them
+    # capacities of the filtered edge lists, measured once over the pool (--capacity-slack head room): with them
     # the step needs no host read-back (live counts, guards and the overflow flag stay on the device)
-    spec = None if args.host_guards else hv.GanTrainer.calibrate(model, [b for b, _ in pool])
+    spec = None if args.host_guards else hv.GanTrainer.calibrate(model, [b for b, _ in pool], slack=args.capacity_slack,
+                                                                 node_slack=min(args.capacity_slack, 1.05))
     capacity = spec.edge_capacity if spec is not None else None
     trainer = hv.GanTrainer(model, edge_capacity=capacity)
     torch.manual_seed(1000 + rank)  # dropout streams differ per rank
@@ -397,10 +402,15 @@ def main():
                        "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
                        if graphed is not None else "kernel time stamps inside the timed region",
                        "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,
+                       "capacities": None if spec is None else
+                       {"slack_over_largest_batch_of_the_pool": args.capacity_slack, "nodes": spec.num_nodes,
+                        "largest_batch_nodes": max(int(b.num_nodes) for b, _ in pool),
+                        "filtered_edges_aa_al_interaction_aa_rows": list(spec.edge_capacity)},
                        "precision": "fp32 throughout" if args.matmul == "fp32" else
                        "dense products on the bf16 matrix instructions with fp32 accumulation: forward products on "
                        "split (hi + lo) bf16 operands, gradient products on bf16 operands; attention, norms, "
-                       "losses, optimizer state and all tensors in memory fp32; every parameter gradient within "
+                       "losses, optimizer state and activations fp32 (gradients that only the gradient products read "
+                       "are kept as bfloat16, which those products round them to anyway); every parameter gradient within "
                        "2e-2 of the float64 oracle (tests/test_gpu_config3.py)"},
             "roofline": roofline, "edge_attention_kernels": extra,
             "losses": {k: float(v) for k, v in logs.items() if v.numel() == 1},

@@ -294,12 +294,16 @@ class GanTrainer:
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def calibrate(model: HiVT, batches: Iterable[TemporalData], slack: float = 1.1, multiple: int = 256) -> BatchSpec:
+    def calibrate(model: HiVT, batches: Iterable[TemporalData], slack: float = 1.1, multiple: int = 256,
+                  node_slack: float = 1.05) -> BatchSpec:
         """A ``BatchSpec`` covering ``batches`` (GPU tensors): tensor capacities from their shapes and
-        filtered-edge capacities from building their edge sets once (one read-back per batch)."""
+        filtered-edge capacities from building their edge sets once (one read-back per batch).  ``slack`` /
+        ``node_slack``: head room over the largest edge / node counts seen, for batches that were not among
+        ``batches`` (every padded row is computed like a real one, so head room costs its share of the step; a
+        batch that does not fit is discarded and flagged)."""
         from .local_encoder import build_edge_plan
         batches = list(batches)
-        spec = BatchSpec.covering(batches)
+        spec = BatchSpec.covering(batches, slack=node_slack)
         worst = [0, 0, 0, 0]
         for b in batches:
             plan = build_edge_plan(b, model.historical_steps, model.local_encoder.local_radius)
