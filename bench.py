@@ -10,9 +10,13 @@ nuScenes-shaped batches of ``--scenes`` scenes (weak scaling).  A step is the wh
 critic update with hinge + R1, generator update.  Rank 0 prints ONE JSON line.
 
 Precision: the named workload is the bf16 one, so by default the dense products take bf16 operands
-with fp32 accumulation (everything else, and all tensors in memory, fp32); ``--matmul fp32`` runs the
-step in fp32 throughout.  The other setting is timed after the headline measurement and reported as
-``matmul_variant``.
+with fp32 accumulation (everything else fp32; in memory only gradients that nothing but those products
+read are bfloat16); ``--matmul fp32`` runs the step in fp32 throughout.  The other setting is timed after
+the headline measurement and reported as ``matmul_variant``.
+
+The step is recorded once as a HIP graph on fixed shapes and replayed: the batches of the pool are padded
+to the pool's largest node / edge counts times ``--capacity-slack`` (``config.capacities``); a batch that
+did not fit would be discarded and counted in ``config.discarded_steps``.
 
 The ``roofline`` object describes the edge-attention launch kind that takes the most time per step:
 algorithmic bytes of one launch divided by its average duration (the kernel's own start / stop time
