@@ -214,6 +214,9 @@ def main():
                     help="dense-scene stress shape instead of the headline workload: 200 agents and 1000 lane "
                          "segments per scene, 150 m radius, every step valid (use with --scenes 2..8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-buckets", dest="buckets", action="store_false",
+                    help="one recording at the pool's largest shape for every batch (default: one recording per distinct "
+                         "padded shape of the pool)")
     ap.add_argument("--capacity-slack", type=float, default=1.0,
                     help="head room of the recorded step's fixed edge / node capacities over the largest batch of the "
                          "pool (1.0: the pool is all the data this run sees; the library's default for a data stream "
@@ -305,7 +308,37 @@ def main():
             if int(ok.item()) == 0:
                 graphed = None
 
+    # Shape buckets: every padded row of a fixed-shape recording is computed like a real one, so a batch replays the
+    # recording of the smallest shape that holds it -- here one recording per distinct shape of the pool (node counts
+    # rounded up to 64, edge lists to 256).  All recordings share the model, the optimizers and their state.  If
+    # any of them cannot be made, the one recording at the pool's largest shape above serves every batch.
+    bucket_of, bucket_graphs, bucket_padded = None, [], []
+    if graphed is not None and args.buckets and world == 1:
+        # (single process only: under data parallelism every recording's warm-up steps hold collectives, and ranks
+        # with different numbers of distinct shapes would issue different numbers of them)
+        try:
+            from hivt_gan_amd.graph import GraphedStep, pack_inputs
+            shapes, bucket_of = {}, []
+            for b, _ in pool:
+                sp = hv.GanTrainer.calibrate(model, [b], slack=args.capacity_slack,
+                                             node_slack=min(args.capacity_slack, 1.05))
+                key = (sp.num_nodes, sp.num_lanes, sp.num_edges, sp.num_lane_actor, tuple(sp.edge_capacity))
+                if key not in shapes:
+                    shapes[key] = len(bucket_graphs)
+                    example = pack_inputs(hv.pad_batch(b, sp))
+                    bucket_graphs.append(GraphedStep(trainer, sp, example, seed_offset=1 + len(bucket_graphs),
+                                                     critic_streams=bool(tuned.get("critic_streams", False))))
+                bucket_of.append(shapes[key])
+                bucket_padded.append(pack_inputs(hv.pad_batch(b, bucket_graphs[shapes[key]].spec)))
+        except Exception as exc:  # noqa: BLE001 -- the single recording stays in use
+            if rank == 0:
+                print(f"warning: shape buckets not recorded ({type(exc).__name__}: {exc})", file=sys.stderr)
+            bucket_of, bucket_graphs, bucket_padded = None, [], []
+
     def run_step(i: int):
+        if bucket_of is not None:
+            j = i % len(bucket_padded)
+            return bucket_graphs[bucket_of[j]].run(bucket_padded[j])
         if graphed is not None:
             return graphed.run(padded[i % len(padded)])
         return eager_step(i)
@@ -353,6 +386,8 @@ def main():
         ops.set_matmul_precision(name)
         if graphed is not None:
             graphed.record()  # the operand precision is part of what a recording fixes
+        for g in bucket_graphs:
+            g.record()
         for i in range(3):
             run_step(i)
         other = (name, timed(args.warmup + args.steps, args.steps))
@@ -401,7 +436,10 @@ def main():
                        "launch": ("recorded HIP graph, %d segment(s) per step (%d kernel + %d copy nodes), inputs copied "
                                   "into its static tensors" % (sum(1 for k, _ in graphed.segments if k == "graph"),
                                                                graphed.nodes.get("kernel", 0),
-                                                               graphed.nodes.get("memcpy", 0)))
+                                                               graphed.nodes.get("memcpy", 0))
+                                  + ("; %d recordings, one per distinct padded shape of the pool (nodes %s)"
+                                     % (len(bucket_graphs), [g.spec.num_nodes for g in bucket_graphs])
+                                     if bucket_of is not None else ""))
                        if graphed is not None else (graph_note or "eager"),
                        "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
                        if graphed is not None else "kernel time stamps inside the timed region",

@@ -111,11 +111,14 @@ class GraphedStep:
     replays on whatever the static inputs hold."""
 
     def __init__(self, trainer, spec: BatchSpec, example: TemporalData, warmup: int = 3,
-                 critic_streams: bool = False) -> None:
+                 critic_streams: bool = False, seed_offset: int = 0) -> None:
         if trainer.edge_capacity is None:
             raise RuntimeError("a recorded step needs the read-back-free mode (GanTrainer(edge_capacity=...))")
         self.trainer = trainer
         self.spec = spec
+        # the capacities this recording was made for: several recordings of one trainer (shape buckets) each
+        # run the step with their own
+        self.edge_capacity = tuple(spec.edge_capacity) if spec.edge_capacity is not None else tuple(trainer.edge_capacity)
         # the static inputs live in one byte buffer (pack_inputs), so that a batch laid out the same way arrives
         # in one copy
         self.static = pack_inputs(TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
@@ -124,7 +127,8 @@ class GraphedStep:
         self._y = self.static["y"]
         dev = self._y.device
         self.device = dev
-        self.seed = torch.zeros((), dtype=torch.int64, device=dev)
+        # (recordings of one trainer start their dropout streams apart)
+        self.seed = torch.full((), int(seed_offset) * 0x5DEECE66D, dtype=torch.int64, device=dev)
         self.critic_streams = bool(critic_streams)
         self.warmup = int(warmup)
         self.nodes: Dict[str, int] = {}
@@ -151,9 +155,11 @@ class GraphedStep:
     def _one_step(self) -> Dict[str, torch.Tensor]:
         t = self.trainer
         prev = (ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS, t._sync_override, t.sync_logs)
+        prev_capacity = t.edge_capacity
         ops.DEVICE_SEED, ops._seed_calls = self.seed, 0
         losses.CONCURRENT_CRITICS = self.critic_streams
         t._sync_override, t.sync_logs = self._sync, False
+        t.edge_capacity = self.edge_capacity
         try:
             self.seed.add_(_SEED_STRIDE)
             self.static["y"] = self._y       # forward rebinds the entry to the rotated targets
@@ -161,6 +167,7 @@ class GraphedStep:
             return t.step(self.static)
         finally:
             ops.DEVICE_SEED, ops._seed_calls, losses.CONCURRENT_CRITICS, t._sync_override, t.sync_logs = prev
+            t.edge_capacity = prev_capacity
 
     def _begin_segment(self) -> None:
         g = torch.cuda.CUDAGraph(keep_graph=True)
