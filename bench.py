@@ -16,7 +16,9 @@ the headline measurement and reported as ``matmul_variant``.
 
 The step is recorded once as a HIP graph on fixed shapes and replayed: the batches of the pool are padded
 to the pool's largest node / edge counts times ``--capacity-slack`` (``config.capacities``); a batch that
-did not fit would be discarded and counted in ``config.discarded_steps``.
+did not fit would be discarded and counted in ``config.discarded_steps``.  Single-process runs make one
+recording per distinct padded shape of the pool and replay, for each batch, the one of its own shape
+(``--no-buckets``: the one recording at the largest shape).
 
 The ``roofline`` object describes the edge-attention launch kind that takes the most time per step:
 algorithmic bytes of one launch divided by its average duration (the kernel's own start / stop time

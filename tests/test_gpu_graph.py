@@ -143,3 +143,39 @@ def test_recorded_data_parallel_step_in_segments_world_of_one():
                 assert torch.equal(v, before[k]), k
     finally:
         dist.destroy_process_group()
+
+
+def test_two_recordings_of_one_trainer_with_their_own_shapes():
+    """Shape buckets: two recordings made on one trainer, each at the padded shape of its own batch, replayed in
+    turn -- the same training run as the eager steps at the larger shape (padding is inert, so only the order of
+    a few sums moves), and neither recording disturbs the trainer's own capacities."""
+    small = hv.make_batch(4, first_index=400).to(DEV)
+    large = hv.make_batch(6, first_index=430).to(DEV)
+    ref_model = make(0.0)
+    spec_all = hv.GanTrainer.calibrate(ref_model, [small, large])
+    padded_all = [hv.pad_batch(small, spec_all), hv.pad_batch(large, spec_all)]
+    # both recordings run three warm-up steps and execute nothing while capturing
+    order = [0, 1, 0, 0, 1]
+    eager_run(ref_model, spec_all, padded_all, [0, 0, 0, 1, 1, 1] + order)
+    model = make(0.0)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec_all.edge_capacity)
+    specs = [hv.GanTrainer.calibrate(model, [b], slack=1.0, node_slack=1.0) for b in (small, large)]
+    assert specs[0].num_nodes < specs[1].num_nodes and specs[0].edge_capacity != specs[1].edge_capacity
+    padded = [hv.pad_batch(b, sp) for b, sp in zip((small, large), specs)]
+    steps = [GraphedStep(trainer, sp, pb, warmup=3, seed_offset=i + 1) for i, (sp, pb) in enumerate(zip(specs, padded))]
+    assert trainer.edge_capacity == tuple(spec_all.edge_capacity)
+    for i in order:
+        logs = steps[i].run(padded[i])
+    torch.cuda.synchronize()
+    assert float(logs["skipped"]) == 0.0 and trainer.overflowed_steps() == 0
+    # compared through what the two models compute on a fresh batch, not parameter by parameter: AdamW turns the
+    # rounding noise of gradients that are zero by construction (the key biases, which a softmax cannot see) into
+    # steps of the size of the learning rate, in a direction that depends on the order of the sums
+    probe = hv.make_batch(3, first_index=470).to(DEV)
+    outs = []
+    for m in (model, ref_model):
+        m.eval()
+        with torch.no_grad():
+            outs.append(m(probe.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), float((a - b).abs().max())
