@@ -16,9 +16,9 @@ the headline measurement and reported as ``matmul_variant``.
 
 The step is recorded once as a HIP graph on fixed shapes and replayed: the batches of the pool are padded
 to the pool's largest node / edge counts times ``--capacity-slack`` (``config.capacities``); a batch that
-did not fit would be discarded and counted in ``config.discarded_steps``.  Single-process runs make one
-recording per distinct padded shape of the pool and replay, for each batch, the one of its own shape
-(``--no-buckets``: the one recording at the largest shape).
+did not fit would be discarded and counted in ``config.discarded_steps``.  A run makes one recording per
+distinct padded shape of the pool (data parallel: one per batch, so that all ranks make equally many) and
+replays, for each batch, the one of its own shape (``--no-buckets``: one recording at the largest shape).
 
 The ``roofline`` object describes the edge-attention launch kind that takes the most time per step:
 algorithmic bytes of one launch divided by its average duration (the kernel's own start / stop time
@@ -315,9 +315,9 @@ def main():
     # rounded up to 64, edge lists to 256).  All recordings share the model, the optimizers and their state.  If
     # any of them cannot be made, the one recording at the pool's largest shape above serves every batch.
     bucket_of, bucket_graphs, bucket_padded = None, [], []
-    if graphed is not None and args.buckets and world == 1:
-        # (single process only: under data parallelism every recording's warm-up steps hold collectives, and ranks
-        # with different numbers of distinct shapes would issue different numbers of them)
+    if graphed is not None and args.buckets:
+        # (under data parallelism every recording's warm-up steps hold collectives, so every rank makes the same
+        # number of recordings: one per batch of its pool, equal shapes or not)
         try:
             from hivt_gan_amd.graph import GraphedStep, pack_inputs
             shapes, bucket_of = {}, []
@@ -325,7 +325,7 @@ def main():
                 sp = hv.GanTrainer.calibrate(model, [b], slack=args.capacity_slack,
                                              node_slack=min(args.capacity_slack, 1.05))
                 key = (sp.num_nodes, sp.num_lanes, sp.num_edges, sp.num_lane_actor, tuple(sp.edge_capacity))
-                if key not in shapes:
+                if key not in shapes or world > 1:
                     shapes[key] = len(bucket_graphs)
                     example = pack_inputs(hv.pad_batch(b, sp))
                     bucket_graphs.append(GraphedStep(trainer, sp, example, seed_offset=1 + len(bucket_graphs),
@@ -336,6 +336,11 @@ def main():
             if rank == 0:
                 print(f"warning: shape buckets not recorded ({type(exc).__name__}: {exc})", file=sys.stderr)
             bucket_of, bucket_graphs, bucket_padded = None, [], []
+        if world > 1:  # all ranks replay their own recordings or none does
+            ok = torch.tensor([1 if bucket_of is not None else 0], device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                bucket_of, bucket_graphs, bucket_padded = None, [], []
 
     def run_step(i: int):
         if bucket_of is not None:
@@ -439,8 +444,9 @@ def main():
                                   "into its static tensors" % (sum(1 for k, _ in graphed.segments if k == "graph"),
                                                                graphed.nodes.get("kernel", 0),
                                                                graphed.nodes.get("memcpy", 0))
-                                  + ("; %d recordings, one per distinct padded shape of the pool (nodes %s)"
-                                     % (len(bucket_graphs), [g.spec.num_nodes for g in bucket_graphs])
+                                  + ("; %d recordings, one per %s of the pool (nodes %s)"
+                                     % (len(bucket_graphs), "distinct padded shape" if world == 1 else "batch",
+                                        [g.spec.num_nodes for g in bucket_graphs])
                                      if bucket_of is not None else ""))
                        if graphed is not None else (graph_note or "eager"),
                        "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
