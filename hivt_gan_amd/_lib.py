@@ -98,11 +98,32 @@ SIGNATURES = {
     "hivt_hinge_r1_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, _P, _P, _P, _P]),
     "hivt_weighted_mean_fwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_weighted_mean_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_batch_prepare": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_int32, c_int32, c_int32,
+                                   c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hivt_row_subset": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, c_int64, _P,
+                                _P, _P, _P, _P, _P, _P]),
+    "hivt_center_rows": (c_int, [_P, _P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "hivt_rows_put_tokens": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, _P]),
+    "hivt_temporal_input_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    "hivt_gather_live_rows": (c_int, [_P, _P, _P, c_int32, c_int32, _P, _P]),
+    "hivt_decoder_output_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P]),
+    "hivt_decoder_output_bwd": (c_int, [_P, _P, c_int64, c_int64, c_int32, c_int32, c_float, _P, _P, _P]),
+    "hivt_category_table_fwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "hivt_category_table_bwd": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
+    "hivt_select_mode_fwd": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "hivt_select_mode_bwd": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "hivt_sum_padded_rows": (c_int, [_P, _P, c_int32, c_int64, c_int32, _P, _P]),
+    "hivt_hinge_r1_multi_fwd": (c_int, [_P, _P, _P, c_int32, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_hinge_r1_multi_bwd": (c_int, [_P, _P, _P, c_int32, _P, _P, c_int64, c_float, _P, _P, _P, _P]),
+    "hivt_generator_total_fwd": (c_int, [_P, _P, c_int32, _P, _P, c_int64, c_float, _P, _P]),
+    "hivt_generator_total_bwd": (c_int, [_P, c_int32, _P, _P, c_int64, c_float, _P, _P, _P]),
     "hivt_set_matmul_bf16": (c_int, [c_int]),
     "hivt_spectral_norm_fwd": (c_int, [c_int32, _P, _P, _P, _P, _P, c_int32, c_float, _P, _P, _P, _P, _P]),
     "hivt_spectral_norm_bwd": (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hivt_step_guards": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P]),
     "hivt_adamw_step": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, _P, c_float, c_float, c_float, c_float, c_float, _P]),
+    "hivt_adamw_update": (c_int, [_P, _P, _P, _P, _P, c_int32, _P, _P, _P, c_float, c_float, c_float, c_float, c_float,
+                                  _P]),
 }
 
 # entry points whose int return value is an answer rather than an error code

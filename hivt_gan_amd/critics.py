@@ -183,9 +183,9 @@ def scores_multi(jobs):
                 weights_of.setdefault(idx, []).append(w)
     passes = []
     for idx, (critic, traj, with_r1) in enumerate(jobs):
-        horizon = getattr(critic, "horizon", None)
-        x = traj if horizon is None else traj[:, :horizon]
-        passes.append((x, weights_of[idx], [m.bias for m in critic._spectral_layers()], with_r1))
+        # the whole trajectory tensor goes down: a pass reads the leading columns its first layer is wide (the
+        # critic's horizon), and passes over one tensor share its gradient
+        passes.append((traj, weights_of[idx], [m.bias for m in critic._spectral_layers()], with_r1))
     first = jobs[0][0]
     slope, drop = first._activation()
     return ops.critic_scores_multi(passes, slope, drop, first.training)

@@ -22,8 +22,10 @@ struct AdamBatch {
   int32_t n[kAdamTensors];           // elements of tensor i
   int32_t first_piece[kAdamTensors + 1];  // prefix sum of the tensors' piece counts
   int32_t count;
-  const float* step;       // device scalar: number of this update (already incremented by the caller)
+  const float* step;       // device scalar: number of this update minus step_offset
+  float step_offset;       // 0: the caller has advanced the counter; 1: the call advances it after the update
   const float* found_inf;  // optional device scalar: 1 -> leave everything as it is
+  const float* lr_ptr;     // optional device scalar that replaces lr
   float lr, beta1, beta2, eps, weight_decay;
 };
 
@@ -40,11 +42,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamBatch a) {
   const float* __restrict__ g = a.g[t];
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
-  const float step = *a.step;
+  const float step = *a.step + a.step_offset;
+  const float lr = a.lr_ptr != nullptr ? *a.lr_ptr : a.lr;
   const float bc1 = 1.0f - powf(a.beta1, step);
   const float bc2_sqrt = sqrtf(1.0f - powf(a.beta2, step));
-  const float step_size = a.lr / bc1;
-  const float decay = 1.0f - a.lr * a.weight_decay;
+  const float step_size = lr / bc1;
+  const float decay = 1.0f - lr * a.weight_decay;
   auto update = [&](float& pi, float grad, float& mi, float& vi) {
     const float param = pi * decay;
     mi = a.beta1 * mi + (1.0f - a.beta1) * grad;
@@ -78,16 +81,46 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamBatch a) {
   }
 }
 
+// step += 1 unless the update was skipped
+__global__ void advance_step_kernel(float* step, const float* found_inf) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(found_inf != nullptr && *found_inf == 1.0f)) *step += 1.0f;
+}
+
 }  // namespace
 }  // namespace hivt
 
 using namespace hivt;
 
+static int adamw_impl(const char* what, const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
+                      const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, const float* step,
+                      float step_offset, const float* found_inf, const float* lr_ptr, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, hivt_stream_t stream);
+
 extern "C" int hivt_adamw_step(const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
                                const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, const float* step,
                                const float* found_inf, float lr, float beta1, float beta2, float eps,
                                float weight_decay, hivt_stream_t stream) {
-  const char* what = "hivt_adamw_step";
+  return adamw_impl("hivt_adamw_step", params, grads, exp_avgs, exp_avg_sqs, numels, count, step, 0.0f, found_inf, nullptr,
+                    lr, beta1, beta2, eps, weight_decay, stream);
+}
+
+extern "C" int hivt_adamw_update(const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
+                                 const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, float* step,
+                                 const float* found_inf, const float* lr_ptr, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, hivt_stream_t stream) {
+  const char* what = "hivt_adamw_update";
+  const int rc = adamw_impl(what, params, grads, exp_avgs, exp_avg_sqs, numels, count, step, 1.0f, found_inf, lr_ptr, lr,
+                            beta1, beta2, eps, weight_decay, stream);
+  if (rc != HIVT_OK || count == 0) return rc;
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, found_inf);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+static int adamw_impl(const char* what, const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
+                      const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, const float* step,
+                      float step_offset, const float* found_inf, const float* lr_ptr, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, hivt_stream_t stream) {
   HIVT_REQUIRE(count >= 0, HIVT_ERR_ARG, "%s: negative tensor count", what);
   if (count == 0) return HIVT_OK;
   HIVT_REQUIRE(params && grads && exp_avgs && exp_avg_sqs && numels && step, HIVT_ERR_ARG, "%s: null pointer", what);
@@ -101,7 +134,7 @@ extern "C" int hivt_adamw_step(const uint64_t* params, const uint64_t* grads, co
   }
   hipStream_t s = (hipStream_t)stream;
   AdamBatch b;
-  b.step = step; b.found_inf = found_inf;
+  b.step = step; b.step_offset = step_offset; b.found_inf = found_inf; b.lr_ptr = lr_ptr;
   b.lr = lr; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps; b.weight_decay = weight_decay;
   int32_t i = 0;
   while (i < count) {

@@ -165,7 +165,7 @@ Scratch carve(const Shape& s, void* ws) {
 
 // one row of the item table of hivt_linear_wgrad_group
 struct Terms {
-  int64_t row[2 * (kMaxHidden + 1)][10];
+  int64_t row[2 * (kMaxHidden + 1) + 8][10];
   int32_t count = 0;
   void add(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N, int32_t K, float* dw,
            float* dbias, bool accumulate, bool joins) {
@@ -253,6 +253,96 @@ __global__ __launch_bounds__(256) void weighted_mean_bwd_kernel(const float* __r
                                                                 float* __restrict__ g_s) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < B) g_s[i] = scale * *g_out * w[i] / *count;
+}
+
+// All critic scales at once (losses/adv_losses.py:36-58 summed over the scales as models/hivt.py:305-310 does):
+// out[0] = sum_k loss_k (added in scale order), out[1 + 2k] = loss_k, out[2 + 2k] = r1_k.  One block.
+constexpr int kMaxScales = 4;
+
+struct ScaleRows {
+  const float* s_real[kMaxScales];
+  const float* grad_norm2[kMaxScales];
+  const float* s_fake[kMaxScales];
+  float* g_real[kMaxScales];
+  float* g_norm2[kMaxScales];
+  float* g_fake[kMaxScales];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void hinge_r1_multi_fwd_kernel(const ScaleRows p, const float* __restrict__ w,
+                                                                 const float* __restrict__ count, int64_t B, float lambda,
+                                                                 float* __restrict__ out) {
+  __shared__ float red[256];
+  float total = 0.0f;
+  for (int k = 0; k < p.count; ++k) {
+    float a = 0.0f, b = 0.0f, c = 0.0f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) {
+      const float wi = w[i];
+      a += fmaxf(1.0f - p.s_real[k][i], 0.0f) * wi;
+      b += fmaxf(1.0f + p.s_fake[k][i], 0.0f) * wi;
+      c += p.grad_norm2[k][i] * wi;
+    }
+    a = block_sum_256(a, red);
+    b = block_sum_256(b, red);
+    c = block_sum_256(c, red);
+    const float cnt = *count;
+    const float r1 = c / cnt;
+    const float loss = (a / cnt + b / cnt) + lambda * r1;
+    total = k == 0 ? loss : total + loss;
+    if (threadIdx.x == 0) {
+      out[1 + 2 * k] = loss;
+      out[2 + 2 * k] = r1;
+    }
+  }
+  if (threadIdx.x == 0) out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void hinge_r1_multi_bwd_kernel(const ScaleRows p, const float* __restrict__ g_loss,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ count, int64_t B, float lambda) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= B) return;
+  const float unit = *g_loss * w[i] / *count;
+  p.g_real[k][i] = (1.0f - p.s_real[k][i] > 0.0f) ? -unit : 0.0f;
+  p.g_fake[k][i] = (1.0f + p.s_fake[k][i] > 0.0f) ? unit : 0.0f;
+  p.g_norm2[k][i] = lambda * unit;
+}
+
+// Generator objective (models/hivt.py:317-324 with losses/adv_losses.py:91-98): out[0] = (losses[0] + losses[1]) +
+// out[1], out[1] = lambda_adv * sum_k out[2 + k], out[2 + k] = -sum_i w_i s_k[i] / count.  One block.
+__global__ __launch_bounds__(256) void generator_total_fwd_kernel(const ScaleRows p, const float* __restrict__ losses,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ count, int64_t B,
+                                                                  float lambda_adv, float* __restrict__ out) {
+  __shared__ float red[256];
+  float total = 0.0f;
+  for (int k = 0; k < p.count; ++k) {
+    float a = 0.0f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) a += p.s_fake[k][i] * w[i];
+    a = block_sum_256(a, red);
+    const float g = -1.0f * (a / *count);
+    total = k == 0 ? g : total + g;
+    if (threadIdx.x == 0) out[2 + k] = g;
+  }
+  if (threadIdx.x == 0) {
+    const float adv = lambda_adv * total;
+    out[1] = adv;
+    out[0] = (losses[0] + losses[1]) + adv;
+  }
+}
+
+__global__ __launch_bounds__(256) void generator_total_bwd_kernel(const ScaleRows p, const float* __restrict__ g_out,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ count, int64_t B,
+                                                                  float lambda_adv, float* __restrict__ g_losses) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  const float g = *g_out;
+  if (blockIdx.x == 0 && k == 0 && threadIdx.x < 2) g_losses[threadIdx.x] = g;
+  if (i >= B) return;
+  const float go = lambda_adv * g;
+  p.g_fake[k][i] = -1.0f * go * w[i] / *count;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -712,6 +802,82 @@ extern "C" int hivt_weighted_mean_bwd(const float* g_out, const float* w, const 
   return HIVT_OK;
 }
 
+extern "C" int hivt_hinge_r1_multi_fwd(const float* const* s_real, const float* const* grad_norm2,
+                                       const float* const* s_fake, int32_t scales, const float* w, const float* count,
+                                       int64_t B, float lambda_r1, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_hinge_r1_multi_fwd";
+  HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
+  HIVT_REQUIRE(count && out && s_real && grad_norm2 && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
+  ScaleRows p{};
+  p.count = scales;
+  for (int k = 0; k < scales; ++k) {
+    HIVT_REQUIRE(B == 0 || (s_real[k] && grad_norm2[k] && s_fake[k]), HIVT_ERR_ARG, "%s: null rows (scale %d)", what, k);
+    p.s_real[k] = s_real[k]; p.grad_norm2[k] = grad_norm2[k]; p.s_fake[k] = s_fake[k];
+  }
+  hipLaunchKernelGGL(hinge_r1_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, w, count, B, lambda_r1, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_hinge_r1_multi_bwd(const float* g_loss, const float* const* s_real, const float* const* s_fake,
+                                       int32_t scales, const float* w, const float* count, int64_t B, float lambda_r1,
+                                       float* const* g_real, float* const* g_norm2, float* const* g_fake,
+                                       hivt_stream_t stream) {
+  const char* what = "hivt_hinge_r1_multi_bwd";
+  HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
+  if (B == 0) return HIVT_OK;
+  HIVT_REQUIRE(g_loss && s_real && s_fake && w && count && g_real && g_norm2 && g_fake, HIVT_ERR_ARG, "%s: null pointer",
+               what);
+  ScaleRows p{};
+  p.count = scales;
+  for (int k = 0; k < scales; ++k) {
+    HIVT_REQUIRE(s_real[k] && s_fake[k] && g_real[k] && g_norm2[k] && g_fake[k], HIVT_ERR_ARG, "%s: null rows (scale %d)",
+                 what, k);
+    p.s_real[k] = s_real[k]; p.s_fake[k] = s_fake[k];
+    p.g_real[k] = g_real[k]; p.g_norm2[k] = g_norm2[k]; p.g_fake[k] = g_fake[k];
+  }
+  hipLaunchKernelGGL(hinge_r1_multi_bwd_kernel, dim3((unsigned)((B + 255) / 256), (unsigned)scales), dim3(256), 0,
+                     (hipStream_t)stream, p, g_loss, w, count, B, lambda_r1);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_generator_total_fwd(const float* losses, const float* const* s_fake, int32_t scales, const float* w,
+                                        const float* count, int64_t B, float lambda_adv, float* out,
+                                        hivt_stream_t stream) {
+  const char* what = "hivt_generator_total_fwd";
+  HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
+  HIVT_REQUIRE(losses && count && out && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
+  ScaleRows p{};
+  p.count = scales;
+  for (int k = 0; k < scales; ++k) {
+    HIVT_REQUIRE(B == 0 || s_fake[k], HIVT_ERR_ARG, "%s: null rows (scale %d)", what, k);
+    p.s_fake[k] = s_fake[k];
+  }
+  hipLaunchKernelGGL(generator_total_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, losses, w, count, B,
+                     lambda_adv, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_generator_total_bwd(const float* g_out, int32_t scales, const float* w, const float* count, int64_t B,
+                                        float lambda_adv, float* g_losses, float* const* g_s, hivt_stream_t stream) {
+  const char* what = "hivt_generator_total_bwd";
+  HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
+  HIVT_REQUIRE(g_out && count && g_losses && g_s && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
+  ScaleRows p{};
+  p.count = scales;
+  for (int k = 0; k < scales; ++k) {
+    HIVT_REQUIRE(B == 0 || g_s[k], HIVT_ERR_ARG, "%s: null rows (scale %d)", what, k);
+    p.g_fake[k] = g_s[k];
+  }
+  const unsigned blocks = (unsigned)((B + 255) / 256 > 0 ? (B + 255) / 256 : 1);
+  hipLaunchKernelGGL(generator_total_bwd_kernel, dim3(blocks, (unsigned)scales), dim3(256), 0, (hipStream_t)stream, p,
+                     g_out, w, count, B, lambda_adv, g_losses);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Several passes per call (all critics, real and generated trajectories): one chain launch for up to six passes.
 // ---------------------------------------------------------------------------------------------
@@ -821,6 +987,7 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
   char* ws = reinterpret_cast<char*>(workspace);
   struct Done { Shape s; BwdPass b; Scratch k; bool chained, scores_chain, penalty_chain, params; };
   std::vector<Done> done;
+  std::vector<char> was_chained((size_t)(count > 0 ? count : 0), 0);
   ChainArgs a{};
   a.neg_slope = neg_slope; a.dropout_p = dropout_p;
   auto flush = [&]() {
@@ -854,11 +1021,7 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
     Done d;
     d.s = s; d.b = b; d.k = carve(s, region); d.chained = true; d.params = params;
     d.scores_chain = b.g_scores != nullptr; d.penalty_chain = b.g_norm2 != nullptr;
-    if (!d.scores_chain) {  // penalty gradients only: the bias gradients (and dx) of the score chain are zero
-      for (int l = 1; l <= s.L; ++l) zero_words(b.dbias[l - 1], s.w[l], st);
-      zero_words(b.dbias[s.L], 1, st);
-      if (b.dx != nullptr) zero_words(b.dx, b.B * s.w[0], st);
-    }
+    if (!d.scores_chain && b.dx != nullptr) zero_words(b.dx, b.B * s.w[0], st);  // dx carries the score chain only
     ChainPass& c = a.pass[a.count];
     c = ChainPass{};
     fill_common(c, s, b.x, b.x_ld, b.w, const_cast<float*>(b.saved));
@@ -867,40 +1030,112 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
     for (int l = 0; l <= s.L; ++l) c.e[l] = d.k.e[l];
     a.first_block[a.count + 1] = a.first_block[a.count] + (int32_t)((s.B + kChainRows - 1) / kChainRows);
     done.push_back(d);
+    was_chained[(size_t)i] = 1;
     if (++a.count == kChainPasses) flush();
   }
   flush();
   HIVT_CHECK_LAUNCH(what);
+  // Passes that were handed the SAME gradient arrays (the passes of one critic over different inputs) sum their
+  // parameter gradients: such passes form a set, found by the address of their first weight gradient.
+  std::vector<std::vector<size_t>> sets;
+  for (size_t i = 0; i < done.size(); ++i) {
+    if (!done[i].params) continue;
+    bool placed = false;
+    for (auto& set : sets)
+      if (done[set[0]].b.dw[0] == done[i].b.dw[0]) {
+        const Done& f = done[set[0]];
+        HIVT_REQUIRE(f.s.L == done[i].s.L, HIVT_ERR_ARG, "%s: passes that share gradients differ in depth", what);
+        for (int l = 0; l <= f.s.L; ++l)
+          HIVT_REQUIRE(f.b.dw[l] == done[i].b.dw[l] && f.b.dbias[l] == done[i].b.dbias[l] && f.s.w[l] == done[i].s.w[l],
+                       HIVT_ERR_ARG, "%s: passes that share gradients must share all of them", what);
+        set.push_back(i);
+        placed = true;
+        break;
+      }
+    if (!placed) sets.push_back({i});
+  }
+  // the passes that took the single-pass route wrote their gradients on their own: they cannot be part of a set
+  for (int32_t i = 0; i < count; ++i) {
+    const int64_t* t = passes + (size_t)i * 12;
+    float* const* dw = as_ptr<float* const>(t[9]);
+    if (dw == nullptr) continue;
+    int sharers = 0;
+    for (int32_t j = 0; j < count; ++j) {
+      float* const* other = as_ptr<float* const>((passes + (size_t)j * 12)[9]);
+      if (other != nullptr && other[0] == dw[0]) ++sharers;
+    }
+    if (sharers < 2 || t[4] == 0) continue;
+    HIVT_REQUIRE(was_chained[(size_t)i] != 0, HIVT_ERR_UNSUPPORTED,
+                 "%s: pass %d shares its gradient arrays with another pass but is not built for the layer chain "
+                 "(at most %d hidden layers, widths that are multiples of 4, a non-empty batch)", what, (int)i,
+                 kChainLayers);
+  }
   // the weight gradients of every chained pass in ONE grouped call; its workspace is what lies behind the passes'
-  // own regions (hivt_critics_bwd_workspace_bytes reserves every pass's share there)
+  // own regions (hivt_critics_bwd_workspace_bytes reserves every pass's share there).  Per weight: the score-chain
+  // terms of the set's passes (the first is the item, the others join it and add their bias sums), then the
+  // penalty-chain terms (no bias).
   std::vector<int64_t> table;
   int32_t terms = 0;
-  for (const Done& d : done) {
-    if (!d.params) continue;
-    const Shape& s = d.s;
-    const BwdPass& b = d.b;
-    Terms t;
-    if (d.scores_chain)
-      t.add(b.g_scores, 1, b.saved + s.h_off[s.L], s.w[s.L], b.B, 1, s.w[s.L], b.dw[s.L], b.dbias[s.L], false, false);
-    for (int l = s.L; l >= 1; --l) {
-      const float* h_prev = l > 1 ? b.saved + s.h_off[l - 1] : b.x;
-      const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : b.x_ld;
-      if (d.scores_chain)
-        t.add(d.k.dz[l], s.w[l], h_prev, h_prev_ld, b.B, s.w[l], s.w[l - 1], b.dw[l - 1], b.dbias[l - 1], false, false);
-      if (d.penalty_chain)
-        t.add(b.saved + s.g_off[l], s.w[l], d.k.e[l - 1], s.w[l - 1], b.B, s.w[l], s.w[l - 1], b.dw[l - 1], nullptr, false,
-              d.scores_chain);
+  for (const auto& set : sets) {
+    const Done& f = done[set[0]];
+    const Shape& s = f.s;
+    bool any_scores = false;
+    for (size_t i : set) any_scores |= done[i].scores_chain;
+    if (!any_scores) {  // penalty gradients only: the bias gradients are zero
+      for (int l = 1; l <= s.L; ++l) zero_words(f.b.dbias[l - 1], s.w[l], st);
+      zero_words(f.b.dbias[s.L], 1, st);
     }
-    table.insert(table.end(), &t.row[0][0], &t.row[0][0] + (size_t)t.count * 10);
-    terms += t.count;
+    Terms t;
+    auto flush_terms = [&]() {
+      table.insert(table.end(), &t.row[0][0], &t.row[0][0] + (size_t)t.count * 10);
+      terms += t.count;
+      t.count = 0;
+    };
+    // output layer: dw_o = g^T h_L, db_o = sum g (a one-column product: not groupable, so later passes add)
+    bool first = true;
+    for (size_t i : set) {
+      const Done& d = done[i];
+      if (!d.scores_chain) continue;
+      t.add(d.b.g_scores, 1, d.b.saved + s.h_off[s.L], s.w[s.L], d.b.B, 1, s.w[s.L], f.b.dw[s.L], f.b.dbias[s.L], !first,
+            false);
+      first = false;
+    }
+    flush_terms();
+    for (int l = s.L; l >= 1; --l) {
+      bool head = true;
+      for (size_t i : set) {
+        const Done& d = done[i];
+        if (!d.scores_chain) continue;
+        const float* h_prev = l > 1 ? d.b.saved + s.h_off[l - 1] : d.b.x;
+        const int64_t h_prev_ld = l > 1 ? s.w[l - 1] : d.b.x_ld;
+        t.add(d.k.dz[l], s.w[l], h_prev, h_prev_ld, d.b.B, s.w[l], s.w[l - 1], f.b.dw[l - 1], f.b.dbias[l - 1], false, !head);
+        if (!head) t.row[t.count - 1][9] |= 8;  // its bias sums count too
+        head = false;
+      }
+      for (size_t i : set) {
+        const Done& d = done[i];
+        if (!d.penalty_chain) continue;
+        t.add(d.b.saved + s.g_off[l], s.w[l], d.k.e[l - 1], s.w[l - 1], d.b.B, s.w[l], s.w[l - 1], f.b.dw[l - 1], nullptr,
+              false, !head);
+        head = false;
+      }
+      flush_terms();
+    }
   }
   if (terms > 0) {
     const size_t left = workspace_bytes - (size_t)(ws - reinterpret_cast<char*>(workspace));
     HIVT_TRY(hivt_linear_wgrad_group(table.data(), terms, ws, left, stream));
   }
-  for (const Done& d : done) {
-    if (!d.params || !d.penalty_chain) continue;
-    reduce_partials(d.k.e[d.s.L], (int)d.b.B, d.s.w[d.s.L], d.b.dw[d.s.L], st, d.scores_chain);
+  for (const auto& set : sets) {
+    bool written = false;
+    for (size_t i : set) written |= done[i].scores_chain;
+    for (size_t i : set) {
+      const Done& d = done[i];
+      if (!d.penalty_chain) continue;
+      // dw_o (+)= column sums of e_L (rows summed in a fixed order)
+      reduce_partials(d.k.e[d.s.L], (int)d.b.B, d.s.w[d.s.L], d.b.dw[d.s.L], st, written);
+      written = true;
+    }
   }
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;

@@ -294,14 +294,17 @@ __global__ __launch_bounds__(kThreads) void linear_wgrad_group_kernel(const Wgra
 // The reductions over the chunks of a group, in the association of reduce_rows_kernel<64, 4>: per term four
 // row slices summed in ascending order and combined in slice order; the terms of an entry are added in term
 // order.  One thread per output column.
+constexpr int kJoinMax = 4;  // an item and up to three terms that join it
+
 struct ReduceEntry {
-  const float* term_base[2];  // partial sums of up to two terms, [chunks][pitch] each
+  const float* term_base[kJoinMax];  // partial sums of up to kJoinMax terms, [chunks][pitch] each
   int64_t pitch;
   float* out;
   float* out1;      // columns at or beyond `split`
   int32_t cols, split;
-  int32_t term_chunks[2];  // term_chunks[1] = 0: one term
+  int32_t term_chunks[kJoinMax];  // term_chunks[t] = 0: no such term
   int32_t accumulate;
+  int32_t K, ld;    // columns of a weight-gradient row and the distance between rows in `out` (ld >= K)
 };
 
 struct ReduceGroup {
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) 
   if (c >= e.cols) return;
   float total = 0.0f;
 #pragma unroll
-  for (int term = 0; term < 2; ++term) {
+  for (int term = 0; term < kJoinMax; ++term) {
     const int R = e.term_chunks[term];
     if (R == 0) continue;
     const float* base = e.term_base[term] + c;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) 
     total = term == 0 ? t : total + t;
   }
   if (c >= e.split && e.out1 == nullptr) return;  // bias columns of an entry without a bias gradient
-  float* dst = c < e.split ? e.out + c : e.out1 + (c - e.split);
+  float* dst = c >= e.split ? e.out1 + (c - e.split) : (e.ld == e.K ? e.out + c : e.out + (int64_t)(c / e.K) * e.ld + c % e.K);
   *dst = e.accumulate ? *dst + total : total;
 }
 
@@ -1070,7 +1073,8 @@ int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int6
 // Several weight gradients per call.  items: count x 10 int64 -- dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none),
 // flags (bit 0: add to what dw / dbias hold; bit 1: this term joins the item before it: same dw, its sum is
 // added to that item's, no bias term of its own; bit 2: dy is bfloat16 in memory, dy_ld in bfloat16 elements,
-// bf16 weight-gradient mode only).  Terms share launches, sixteen per launch, long chunks
+// bf16 weight-gradient mode only; bit 3, on a joining term: its column sums of dy count towards the item's dbias;
+// bit 4: dw is one half of a [N, 2K] matrix, its rows 2K floats apart).  Terms share launches, sixteen per launch, long chunks
 // first.  A term that hivt_linear_wgrad would cut into fewer than 64 row chunks gets the same chunks and the
 // same order of sums here (bit-identical results); a longer one is summed in chunks of about 2048 rows (equal
 // to rounding).  Terms whose operands do not allow 16-byte loads go through the single-product path one by one.
@@ -1079,7 +1083,9 @@ namespace {
 
 struct GroupItem {
   const float* dy; int64_t dy_ld; const float* x; int64_t x_ld; int64_t M; int32_t N, K; float* dw; float* dbias;
-  bool accumulate, joins, dy_half;
+  bool accumulate, joins, dy_half, join_bias;
+  bool wide_rows;                 // dw is one half of a [N, 2K] matrix: its rows are 2K apart
+  int head;                       // index of the item a joining term adds to (its own index otherwise)
   int chunks, chunk_rows, tiles;  // of the single-product path
   bool groupable;
   size_t ws_floats;               // its share of the workspace
@@ -1097,14 +1103,19 @@ int parse_group(const char* what, const int64_t* items, int32_t count, std::vect
     g.M = t[4]; g.N = (int32_t)t[5]; g.K = (int32_t)t[6];
     g.dw = reinterpret_cast<float*>((uintptr_t)t[7]); g.dbias = reinterpret_cast<float*>((uintptr_t)t[8]);
     g.accumulate = (t[9] & 1) != 0; g.joins = (t[9] & 2) != 0; g.dy_half = (t[9] & 4) != 0;
+    g.join_bias = g.joins && (t[9] & 8) != 0;
+    g.wide_rows = (t[9] & 16) != 0;
+    g.head = i;
     HIVT_REQUIRE(g.M >= 0 && g.M < ((int64_t)1 << 31) && t[5] > 0 && t[6] > 0 && t[5] < ((int64_t)1 << 24) &&
                  t[6] < ((int64_t)1 << 24), HIVT_ERR_ARG, "%s: item %d: bad sizes", what, (int)i);
     HIVT_REQUIRE(g.dw != nullptr, HIVT_ERR_ARG, "%s: item %d: dw is null", what, (int)i);
     HIVT_REQUIRE(g.M == 0 || (g.dy && g.x), HIVT_ERR_ARG, "%s: item %d: null operand", what, (int)i);
     if (g.joins) {
-      HIVT_REQUIRE(i > 0 && !out[(size_t)i - 1].joins && out[(size_t)i - 1].dw == g.dw && out[(size_t)i - 1].N == g.N &&
-                   out[(size_t)i - 1].K == g.K, HIVT_ERR_ARG,
-                   "%s: item %d joins an item that is not a plain item with the same dw and sizes", what, (int)i);
+      HIVT_REQUIRE(i > 0 && out[(size_t)i - 1].dw == g.dw && out[(size_t)i - 1].N == g.N && out[(size_t)i - 1].K == g.K,
+                   HIVT_ERR_ARG, "%s: item %d joins an item with another dw or other sizes", what, (int)i);
+      g.head = out[(size_t)i - 1].head;
+      HIVT_REQUIRE(i - g.head < kJoinMax, HIVT_ERR_ARG, "%s: item %d: at most %d terms join one item", what, (int)i,
+                   kJoinMax - 1);
       g.dbias = nullptr;
     }
     g.tiles = ((g.N + 63) / 64) * ((g.K + 127) / 128);
@@ -1129,10 +1140,18 @@ int parse_group(const char* what, const int64_t* items, int32_t count, std::vect
                  "%s: item %d: a bfloat16 dy needs the bf16 weight-gradient mode and operands that allow wide loads",
                  what, (int)i);
   }
-  // an entry (an item and the one that joins it) goes through the grouped kernels only as a whole
+  // an entry (an item and the terms that join it) goes through the grouped kernels only as a whole
   for (int32_t i = 0; i < count; ++i)
-    if (out[(size_t)i].joins && !(out[(size_t)i].groupable && out[(size_t)i - 1].groupable))
-      out[(size_t)i].groupable = out[(size_t)i - 1].groupable = false;
+    if (out[(size_t)i].joins && !out[(size_t)i].groupable) out[(size_t)out[(size_t)i].head].groupable = false;
+  for (int32_t i = 0; i < count; ++i)
+    if (out[(size_t)i].joins && !out[(size_t)out[(size_t)i].head].groupable) out[(size_t)i].groupable = false;
+  for (int32_t i = 0; i < count; ++i)
+    HIVT_REQUIRE(!(out[(size_t)i].wide_rows && !out[(size_t)i].groupable), HIVT_ERR_UNSUPPORTED,
+                 "%s: item %d: a gradient with wide rows needs a non-empty term whose operands allow 16-byte loads", what,
+                 (int)i);
+  for (int32_t i = 0; i < count; ++i)
+    HIVT_REQUIRE(!(out[(size_t)i].join_bias && !out[(size_t)i].groupable && out[(size_t)i].M > 0), HIVT_ERR_UNSUPPORTED,
+                 "%s: item %d: a joining term with bias sums needs operands that allow 16-byte loads", what, (int)i);
   return HIVT_OK;
 }
 
@@ -1192,7 +1211,7 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
   auto add_product = [&](int32_t i) {
     const GroupItem& it = g[(size_t)i];
     // a joining term lays its chunks out like the item it joins (bias slots included, cleared)
-    const GroupItem& head = it.joins ? g[(size_t)i - 1] : it;
+    const GroupItem& head = g[(size_t)it.head];
     const int64_t pitch = (int64_t)head.N * head.K + (head.dbias ? head.N : 0);
     float* base = region[(size_t)i];
     WgradArgs a{};
@@ -1204,13 +1223,13 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
     a.bias_partial = head.dbias ? base + (size_t)it.N * it.K : nullptr;
     a.N = it.N; a.K = it.K; a.M = (int32_t)it.M; a.chunk_rows = it.chunk_rows;
     wg.item[wg.count] = a;
-    wg.zero_bias[wg.count] = it.joins ? 1 : 0;
+    wg.zero_bias[wg.count] = (it.joins && !it.join_bias) ? 1 : 0;
     wg.first_block[wg.count + 1] = wg.first_block[wg.count] + it.tiles * it.chunks;
     if (++wg.count == kGroupMax) flush_products();
   };
   for (int32_t i : order) {
     add_product(i);
-    if (i + 1 < count && g[(size_t)i + 1].joins) add_product(i + 1);
+    for (int32_t j = i + 1; j < count && g[(size_t)j].joins; ++j) add_product(j);
   }
   flush_products();
   HIVT_CHECK_LAUNCH(what);
@@ -1224,15 +1243,17 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
   for (int32_t i = 0; i < count; ++i) {
     const GroupItem& it = g[(size_t)i];
     if (!it.groupable || it.joins) continue;
-    const bool joined = i + 1 < count && g[(size_t)i + 1].joins;
     ReduceEntry e{};
     e.term_base[0] = region[(size_t)i];
-    e.term_base[1] = joined ? region[(size_t)i + 1] : nullptr;
+    e.term_chunks[0] = it.chunks;
+    for (int32_t j = i + 1, t = 1; j < count && g[(size_t)j].joins; ++j, ++t) {
+      e.term_base[t] = region[(size_t)j];
+      e.term_chunks[t] = g[(size_t)j].chunks;
+    }
     e.pitch = (int64_t)it.N * it.K + (it.dbias ? it.N : 0);
     e.out = it.dw; e.out1 = it.dbias;
     e.cols = (int32_t)e.pitch; e.split = it.N * it.K;
-    e.term_chunks[0] = it.chunks;
-    e.term_chunks[1] = joined ? g[(size_t)i + 1].chunks : 0;
+    e.K = it.K; e.ld = it.wide_rows ? 2 * it.K : it.K;
     e.accumulate = it.accumulate ? 1 : 0;
     rg.e[rg.count] = e;
     rg.first_block[rg.count + 1] = rg.first_block[rg.count] + (e.cols + 255) / 256;

@@ -1,0 +1,626 @@
+// Row bookkeeping around the edge-attention stages: everything the step used to do with a few dozen tiny
+// framework launches each (index arithmetic, masks, gathers of token rows, assembling the decoder's output) as
+// one launch per job.  All of it is HBM / latency bound integer and copy work; nothing here is shaped into a
+// product.
+//
+//   batch_prepare      rotation matrices, rotated targets and histories, lane codes, per-agent loss weights
+//   row_subset         packed (step, agent) nodes of the agent-agent stage + the plan's overflow flag
+//   center_rows        rotated displacement and begin-of-sequence code of every packed node
+//   rows_put_tokens    rows replaced by token rows (begin-of-sequence tokens), and the gradient's mask
+//   temporal_input     packed rows -> [T + 1, N, D] with padding / class tokens and the positional rows
+//   decoder_output     (loc, raw scale) -> [.., H, 4] trajectories with the scale's ELU + 1 and floor
+//   select_mode        best-mode trajectories out of [F, N, H, 4], and their gradient added back in place
+//   sum_padded_rows    sum of row blocks of different widths (the critics' input gradients)
+#include "common.h"
+
+#include <math.h>
+
+namespace hivt {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// batch_prepare (models/hivt.py:153-162, models/local_encoder.py:135-149,332-334, models/hivt.py:227-231)
+// ---------------------------------------------------------------------------------------------
+struct PrepareArgs {
+  const float* angles;      // [N]
+  const float* y;           // [N, Hf, 2] or null
+  const float* x;           // [N, *, 2] with element strides x_sn, x_st
+  int64_t x_sn, x_st;
+  const uint8_t* pm;        // [N, pm_stride]
+  int64_t pm_stride;
+  const uint8_t* is_int;    // [L]
+  const uint8_t* turn;
+  const uint8_t* ctrl;
+  int32_t N, T, Hf, L;
+  float* rot;               // [N, 2, 2]
+  float* y_rot;             // [N, Hf, 2]
+  float* x_rot;             // [T * N, 2], row t * N + n
+  float* x_steps;           // [T * N, 2]: x itself in that row order
+  int32_t* lane_code;       // [L]
+  float* keep_w;            // [N]
+  float* keep_count;        // [1]
+};
+
+// row vector (a, b) times [[c, -s], [s, c]], products and sum rounded separately (as the framework's
+// elementwise operators do)
+__device__ __forceinline__ float2 rotate_row(float a, float b, float c, float s) {
+#pragma clang fp contract(off)  // no fused multiply-add: three roundings per component, as three operators give
+  const float ac = a * c, bs = b * s, as = a * -s, bc = b * c;
+  return make_float2(ac + bs, as + bc);
+}
+
+__device__ __forceinline__ bool any_future(const PrepareArgs& a, int n) {
+  const uint8_t* row = a.pm + (int64_t)n * a.pm_stride + a.T;
+  bool keep = false;
+  for (int h = 0; h < a.Hf; ++h) keep |= row[h] == 0;
+  return keep;
+}
+
+__global__ __launch_bounds__(256) void batch_prepare_kernel(const PrepareArgs a) {
+  __shared__ float red[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < a.N) {
+    const float ang = a.angles[i];
+    const float s = sinf(ang), c = cosf(ang);
+    *reinterpret_cast<float4*>(a.rot + 4 * i) = make_float4(c, -s, s, c);
+    a.keep_w[i] = any_future(a, (int)i) ? 1.0f : 0.0f;
+  }
+  if (i < (int64_t)a.N * a.T) {  // i = n * T + t: reads of x are contiguous
+    const int n = (int)(i / a.T), t = (int)(i - (int64_t)n * a.T);
+    const float ang = a.angles[n];
+    const float s = sinf(ang), c = cosf(ang);
+    const float2 v = *reinterpret_cast<const float2*>(a.x + (int64_t)n * a.x_sn + (int64_t)t * a.x_st);
+    *reinterpret_cast<float2*>(a.x_rot + 2 * ((int64_t)t * a.N + n)) = rotate_row(v.x, v.y, c, s);
+    *reinterpret_cast<float2*>(a.x_steps + 2 * ((int64_t)t * a.N + n)) = v;
+  }
+  if (a.y != nullptr && i < (int64_t)a.N * a.Hf) {
+    const int n = (int)(i / a.Hf);
+    const float ang = a.angles[n];
+    const float s = sinf(ang), c = cosf(ang);
+    const float2 v = *reinterpret_cast<const float2*>(a.y + 2 * i);
+    *reinterpret_cast<float2*>(a.y_rot + 2 * i) = rotate_row(v.x, v.y, c, s);
+  }
+  if (i < a.L) a.lane_code[i] = ((int)a.is_int[i] * 3 + (int)a.turn[i]) * 2 + (int)a.ctrl[i];
+  if (blockIdx.x == 0) {  // number of agents with a future step, at least one; fixed order of sums
+    float cnt = 0.0f;
+    for (int n = threadIdx.x; n < a.N; n += 256) cnt += any_future(a, n) ? 1.0f : 0.0f;
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+      if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.keep_count[0] = fmaxf(red[0], 1.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row_subset: the nodes (t, n) with padding_mask[n][t] == 0, packed in ascending node id t * N + n
+// ---------------------------------------------------------------------------------------------
+struct SubsetArgs {
+  const uint8_t* pm;
+  int64_t pm_stride;
+  int32_t N, T, capacity;
+  const int32_t* rowptr;         // [T * N + 1] or null
+  const int32_t* edge_count[3];  // optional device counters checked against edge_cap
+  int64_t edge_cap[3];
+  int32_t* rows;                 // [capacity]
+  int32_t* new_id;               // [T * N]
+  uint8_t* live;                 // [capacity]
+  int32_t* count;                // [2]: live rows, id of the first live row
+  int32_t* packed_rowptr;        // [capacity + 1] or null
+  uint8_t* overflow;             // [1]
+};
+
+__device__ __forceinline__ int node_valid(const SubsetArgs& a, int64_t m) {
+  const int64_t t = m / a.N, n = m - t * a.N;
+  return a.pm[n * a.pm_stride + t] == 0 ? 1 : 0;
+}
+
+// One block: inclusive count of valid nodes up to each node (left in new_id), the total and the first valid node.
+__global__ __launch_bounds__(1024) void subset_scan_kernel(const SubsetArgs a) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int64_t M = (int64_t)a.N * a.T;
+  const int64_t per = (M + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * per;
+  const int64_t hi = lo + per < M ? lo + per : M;
+  int s = 0;
+  for (int64_t m = lo; m < hi; ++m) s += node_valid(a, m);
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid == 0 ? 0 : part[tid - 1];
+  for (int64_t m = lo; m < hi; ++m) {
+    const int v = node_valid(a, m);
+    if (v && run == 0) a.count[1] = (int32_t)m;
+    run += v;
+    a.new_id[m] = run;
+  }
+  if (tid == 1023) {
+    a.count[0] = part[1023];
+    if (part[1023] == 0) a.count[1] = (int32_t)(M > 0 ? M - 1 : 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void subset_fill_kernel(const SubsetArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t M = (int64_t)a.N * a.T;
+  const int32_t count = a.count[0];
+  const int32_t packed = count < a.capacity ? count : a.capacity;
+  if (i < M) {
+    const int32_t p = a.new_id[i] - 1;
+    if (node_valid(a, i) && p < a.capacity) {
+      a.rows[p] = (int32_t)i;
+      if (a.packed_rowptr != nullptr) a.packed_rowptr[p] = a.rowptr[i];
+    }
+    a.new_id[i] = p < 0 ? 0 : (p < a.capacity ? p : a.capacity - 1);
+  }
+  if (i < a.capacity) {
+    a.live[i] = i < count ? 1 : 0;
+    if (i >= packed) a.rows[i] = a.count[1];  // a valid node id: gathers through it stay finite
+  }
+  if (a.packed_rowptr != nullptr && i >= packed && i <= a.capacity) a.packed_rowptr[i] = a.rowptr[M];
+  if (i == 0) {
+    bool over = count > a.capacity;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (a.edge_count[k] != nullptr) over |= (int64_t)*a.edge_count[k] > a.edge_cap[k];
+    a.overflow[0] = over ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// center_rows / rows_put_tokens (models/local_encoder.py:149-150)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_rows_kernel(const float* __restrict__ x_rot, const uint8_t* __restrict__ bos,
+                                                          int64_t bos_stride, const int32_t* __restrict__ rows, int32_t N,
+                                                          int32_t capacity, float* __restrict__ xc,
+                                                          int32_t* __restrict__ code) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= capacity) return;
+  const int32_t m = rows[i];
+  const int32_t t = m / N, n = m - t * N;
+  *reinterpret_cast<float2*>(xc + 2 * (int64_t)i) = *reinterpret_cast<const float2*>(x_rot + 2 * (int64_t)m);
+  code[i] = bos[(int64_t)n * bos_stride + t] ? t : -1;
+}
+
+// out[m] = code[m] >= 0 ? token[code[m]] : x[m]   (x == null: rows without a code become zero; that is the
+// gradient's form: pass the negated selection)
+__global__ __launch_bounds__(256) void rows_put_tokens_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                              const int32_t* __restrict__ code,
+                                                              const float* __restrict__ token, int64_t M, int32_t D4,
+                                                              int32_t keep_coded, float* __restrict__ out) {
+  const int64_t total = M * D4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / D4;
+    const int c = (int)(i - m * D4) * 4;
+    const int32_t k = code[m];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (token != nullptr) {
+      v = k >= 0 ? *reinterpret_cast<const float4*>(token + (int64_t)k * D4 * 4 + c)
+                 : *reinterpret_cast<const float4*>(x + m * x_ld + c);
+    } else if ((k >= 0) == (keep_coded != 0)) {
+      v = *reinterpret_cast<const float4*>(x + m * x_ld + c);
+    }
+    *reinterpret_cast<float4*>(out + m * (int64_t)D4 * 4 + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// temporal_input (models/local_encoder.py:230-232)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void temporal_input_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ new_id,
+                                                                 const uint8_t* __restrict__ pm, int64_t pm_stride,
+                                                                 const float* __restrict__ pad_token,
+                                                                 const float* __restrict__ cls,
+                                                                 const float* __restrict__ pos, int32_t T, int32_t N,
+                                                                 int32_t D4, float* __restrict__ out,
+                                                                 int32_t* __restrict__ pad_code) {
+  const int64_t total = (int64_t)(T + 1) * N * D4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / D4;
+    const int c = (int)(i - m * D4) * 4;
+    const int s = (int)(m / N), n = (int)(m - (int64_t)s * N);
+    float4 v;
+    int code = -1;
+    if (s == T) {
+      v = *reinterpret_cast<const float4*>(cls + c);
+    } else if (pm[(int64_t)n * pm_stride + s]) {
+      v = *reinterpret_cast<const float4*>(pad_token + (int64_t)s * D4 * 4 + c);
+      code = s;
+    } else {
+      v = *reinterpret_cast<const float4*>(x + (int64_t)(new_id != nullptr ? new_id[m] : (int32_t)m) * D4 * 4 + c);
+    }
+    const float4 p = *reinterpret_cast<const float4*>(pos + (int64_t)s * D4 * 4 + c);
+    *reinterpret_cast<float4*>(out + m * (int64_t)D4 * 4 + c) = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+    if (c == 0) pad_code[m] = code;
+  }
+}
+
+// dx[r] = live row r ? dy[rows[r]] : 0
+__global__ __launch_bounds__(256) void gather_live_rows_kernel(const float* __restrict__ dy, const int32_t* __restrict__ rows,
+                                                               const int32_t* __restrict__ count, int32_t capacity,
+                                                               int32_t D4, float* __restrict__ dx) {
+  const int64_t total = (int64_t)capacity * D4;
+  const int32_t live = *count;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / D4;
+    const int c = (int)(i - r * D4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < live) v = *reinterpret_cast<const float4*>(dy + (int64_t)rows[r] * D4 * 4 + c);
+    *reinterpret_cast<float4*>(dx + r * (int64_t)D4 * 4 + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder_output (models/decoder.py:131-139)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float scale_value(float v, float floor_) {
+  const float e = v > 0.0f ? v : expm1f(v);
+  return fmaxf(e + 1.0f, floor_);
+}
+
+// input row m of the mode-major output row o: the inputs are either in the same order (F <= 1) or agent-major
+// (row n * F + f for output row f * N + n)
+__device__ __forceinline__ int64_t input_row(int64_t o, int64_t M, int32_t F) {
+  if (F <= 1) return o;
+  const int64_t N = M / F, f = o / N, n = o - f * N;
+  return n * F + f;
+}
+
+__global__ __launch_bounds__(256) void decoder_output_fwd_kernel(const float* __restrict__ loc, int64_t loc_ld,
+                                                                 const float* __restrict__ raw, int64_t raw_ld,
+                                                                 int64_t M, int32_t H, int32_t F, float floor_,
+                                                                 float* __restrict__ out) {
+  const int64_t total = M * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i / H;
+    const int h = (int)(i - o * H);
+    const int64_t m = input_row(o, M, F);
+    const float2 l = *reinterpret_cast<const float2*>(loc + m * loc_ld + 2 * h);
+    const float2 r = *reinterpret_cast<const float2*>(raw + m * raw_ld + 2 * h);
+    *reinterpret_cast<float4*>(out + 4 * i) = make_float4(l.x, l.y, scale_value(r.x, floor_), scale_value(r.y, floor_));
+  }
+}
+
+__device__ __forceinline__ float scale_grad(float v, float g, float floor_) {
+  const float e = v > 0.0f ? v : expm1f(v);
+  if (!(e + 1.0f >= floor_)) return 0.0f;
+  return v > 0.0f ? g : g * expf(v);
+}
+
+__global__ __launch_bounds__(256) void decoder_output_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ raw,
+                                                                 int64_t raw_ld, int64_t M, int32_t H, int32_t F,
+                                                                 float floor_, float* __restrict__ dloc,
+                                                                 float* __restrict__ draw) {
+  const int64_t total = M * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i / H;
+    const int h = (int)(i - o * H);
+    const int64_t m = input_row(o, M, F);
+    const float4 g = *reinterpret_cast<const float4*>(dout + 4 * i);
+    const float2 r = *reinterpret_cast<const float2*>(raw + m * raw_ld + 2 * h);
+    *reinterpret_cast<float2*>(dloc + m * 2 * H + 2 * h) = make_float2(g.x, g.y);
+    *reinterpret_cast<float2*>(draw + m * 2 * H + 2 * h) =
+        make_float2(scale_grad(r.x, g.z, floor_), scale_grad(r.y, g.w, floor_));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_mode (models/hivt.py:221-224)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_mode_fwd_kernel(const float* __restrict__ y_hat, const int64_t* __restrict__ best,
+                                                              int32_t F, int32_t N, int32_t H, int32_t C,
+                                                              float* __restrict__ out) {
+  const int64_t total = (int64_t)N * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / H;
+    int64_t f = best[n];
+    f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+    *reinterpret_cast<float2*>(out + 2 * i) = *reinterpret_cast<const float2*>(y_hat + ((f * N) * H + i) * C);
+  }
+}
+
+// d_y_hat[best[n], n, h, 0:2] += g[n, h, :]
+__global__ __launch_bounds__(256) void select_mode_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ best,
+                                                              int32_t F, int32_t N, int32_t H, int32_t C,
+                                                              float* __restrict__ d_y_hat) {
+  const int64_t total = (int64_t)N * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / H;
+    int64_t f = best[n];
+    f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+    float2* dst = reinterpret_cast<float2*>(d_y_hat + ((f * N) * H + i) * C);
+    const float2 a = *dst, b = *reinterpret_cast<const float2*>(g + 2 * i);
+    *dst = make_float2(a.x + b.x, a.y + b.y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum_padded_rows: out[b][c] = sum over parts p with c < width[p] of part[p][b][c], parts added in order
+// ---------------------------------------------------------------------------------------------
+struct PaddedParts {
+  const float* part[4];
+  int32_t width[4];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void sum_padded_rows_kernel(const PaddedParts p, int64_t B, int32_t W,
+                                                              float* __restrict__ out) {
+  const int64_t total = B * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / W;
+    const int c = (int)(i - b * W);
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < p.count && c < p.width[k]) s += p.part[k][b * p.width[k] + c];
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// category_table: the 12 sums a[i] + b[j] + c[k] of three small embedding tables (models/local_encoder.py:361-363)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void category_table_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 const float* __restrict__ c, int32_t na, int32_t nb,
+                                                                 int32_t nc, int32_t D, float* __restrict__ out) {
+  const int total = na * nb * nc * D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int col = i % D, row = i / D;
+    const int k = row % nc, j = (row / nc) % nb, ia = row / (nc * nb);
+    out[i] = (a[ia * D + col] + b[j * D + col]) + c[k * D + col];
+  }
+}
+
+// da[i] = sum over (j, k) of g[(i nb + j) nc + k], likewise db, dc: rows added in ascending order
+__global__ __launch_bounds__(256) void category_table_bwd_kernel(const float* __restrict__ g, int32_t na, int32_t nb,
+                                                                 int32_t nc, int32_t D, float* __restrict__ da,
+                                                                 float* __restrict__ db, float* __restrict__ dc) {
+  const int total = (na + nb + nc) * D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int col = i % D, r = i / D;
+    float s = 0.0f;
+    for (int row = 0; row < na * nb * nc; ++row) {
+      const int k = row % nc, j = (row / nc) % nb, ia = row / (nc * nb);
+      const bool mine = r < na ? ia == r : (r < na + nb ? j == r - na : k == r - na - nb);
+      if (mine) s += g[row * D + col];
+    }
+    if (r < na) da[r * D + col] = s;
+    else if (r < na + nb) db[(r - na) * D + col] = s;
+    else dc[(r - na - nb) * D + col] = s;
+  }
+}
+
+inline unsigned grid_for(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+}  // namespace
+}  // namespace hivt
+
+using namespace hivt;
+
+extern "C" int hivt_batch_prepare(const float* rotate_angles, const float* y, const float* x, int64_t x_stride_n,
+                                  int64_t x_stride_t, const uint8_t* padding_mask, int64_t pm_stride,
+                                  const uint8_t* is_intersections, const uint8_t* turn_directions,
+                                  const uint8_t* traffic_controls, int32_t N, int32_t T, int32_t Hf, int32_t L,
+                                  float* rotate_mat, float* y_rot, float* x_rot, float* x_steps, int32_t* lane_code,
+                                  float* keep_w, float* keep_count, hivt_stream_t stream) {
+  const char* what = "hivt_batch_prepare";
+  HIVT_REQUIRE(N >= 0 && T > 0 && Hf >= 0 && L >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(keep_count != nullptr, HIVT_ERR_ARG, "%s: keep_count is null", what);
+  HIVT_REQUIRE(N == 0 || (rotate_angles && x && padding_mask && rotate_mat && x_rot && x_steps && keep_w), HIVT_ERR_ARG,
+               "%s: null pointer", what);
+  HIVT_REQUIRE(y == nullptr || y_rot != nullptr, HIVT_ERR_ARG, "%s: y without y_rot", what);
+  HIVT_REQUIRE(L == 0 || (is_intersections && turn_directions && traffic_controls && lane_code), HIVT_ERR_ARG,
+               "%s: null lane attribute", what);
+  HIVT_REQUIRE(pm_stride >= T + Hf, HIVT_ERR_ARG, "%s: padding_mask rows shorter than T + Hf", what);
+  HIVT_REQUIRE(N == 0 || (al8(x) && al8(x_rot) && al8(x_steps) && al16(rotate_mat) && x_stride_n % 2 == 0 && x_stride_t % 2 == 0 &&
+                          (y == nullptr || (al8(y) && al8(y_rot)))),
+               HIVT_ERR_ARG, "%s: rows of x / y must start on 8-byte boundaries (rotate_mat on 16)", what);
+  PrepareArgs a{};
+  a.angles = rotate_angles; a.y = y; a.x = x; a.x_sn = x_stride_n; a.x_st = x_stride_t;
+  a.pm = padding_mask; a.pm_stride = pm_stride;
+  a.is_int = is_intersections; a.turn = turn_directions; a.ctrl = traffic_controls;
+  a.N = N; a.T = T; a.Hf = Hf; a.L = L;
+  a.rot = rotate_mat; a.y_rot = y_rot; a.x_rot = x_rot; a.x_steps = x_steps; a.lane_code = lane_code; a.keep_w = keep_w;
+  a.keep_count = keep_count;
+  int64_t items = (int64_t)N * (T > Hf ? T : Hf);
+  if (items < L) items = L;
+  if (items < N) items = N;
+  hipLaunchKernelGGL(batch_prepare_kernel, dim3((unsigned)((items + 255) / 256 > 0 ? (items + 255) / 256 : 1)), dim3(256),
+                     0, (hipStream_t)stream, a);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_row_subset(const uint8_t* padding_mask, int64_t pm_stride, int32_t N, int32_t T, int32_t capacity,
+                               const int32_t* rowptr, const int32_t* edge_count0, int64_t edge_cap0,
+                               const int32_t* edge_count1, int64_t edge_cap1, const int32_t* edge_count2,
+                               int64_t edge_cap2, int32_t* rows, int32_t* new_id, uint8_t* live, int32_t* count,
+                               int32_t* packed_rowptr, uint8_t* overflow, hivt_stream_t stream) {
+  const char* what = "hivt_row_subset";
+  HIVT_REQUIRE(N > 0 && T > 0 && capacity > 0 && (int64_t)N * T < ((int64_t)1 << 31), HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(padding_mask && rows && new_id && live && count && overflow, HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(pm_stride >= T, HIVT_ERR_ARG, "%s: padding_mask rows shorter than T", what);
+  HIVT_REQUIRE((rowptr == nullptr) == (packed_rowptr == nullptr), HIVT_ERR_ARG,
+               "%s: rowptr and packed_rowptr go together", what);
+  SubsetArgs a{};
+  a.pm = padding_mask; a.pm_stride = pm_stride; a.N = N; a.T = T; a.capacity = capacity; a.rowptr = rowptr;
+  a.edge_count[0] = edge_count0; a.edge_count[1] = edge_count1; a.edge_count[2] = edge_count2;
+  a.edge_cap[0] = edge_cap0; a.edge_cap[1] = edge_cap1; a.edge_cap[2] = edge_cap2;
+  a.rows = rows; a.new_id = new_id; a.live = live; a.count = count; a.packed_rowptr = packed_rowptr;
+  a.overflow = overflow;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(subset_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+  HIVT_CHECK_LAUNCH(what);
+  int64_t items = (int64_t)N * T;
+  if (items < (int64_t)capacity + 1) items = (int64_t)capacity + 1;
+  hipLaunchKernelGGL(subset_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_center_rows(const float* x_rot, const uint8_t* bos_mask, int64_t bos_stride, const int32_t* rows,
+                                int32_t N, int32_t T, int32_t capacity, float* xc, int32_t* code,
+                                hivt_stream_t stream) {
+  const char* what = "hivt_center_rows";
+  HIVT_REQUIRE(N > 0 && T > 0 && capacity >= 0 && bos_stride >= T, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (capacity == 0) return HIVT_OK;
+  HIVT_REQUIRE(x_rot && bos_mask && rows && xc && code && al8(x_rot) && al8(xc), HIVT_ERR_ARG, "%s: null / unaligned pointer",
+               what);
+  hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x_rot, bos_mask, bos_stride, rows, N, capacity, xc, code);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_rows_put_tokens(const float* x, int64_t x_ld, const int32_t* code, const float* token, int64_t M,
+                                    int32_t D, int32_t keep_coded, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_rows_put_tokens";
+  HIVT_REQUIRE(M >= 0 && D > 0 && D % 4 == 0, HIVT_ERR_ARG, "%s: the width must be a multiple of 4", what);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(x && code && out && al16(x) && al16(out) && x_ld % 4 == 0 && (token == nullptr || al16(token)),
+               HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(rows_put_tokens_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, (hipStream_t)stream, x, x_ld,
+                     code, token, M, D / 4, keep_coded, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_temporal_input_fwd(const float* x, const int32_t* new_id, const uint8_t* padding_mask,
+                                       int64_t pm_stride, const float* padding_token, const float* cls_token,
+                                       const float* pos_embed, int32_t T, int32_t N, int32_t D, float* out,
+                                       int32_t* pad_code, hivt_stream_t stream) {
+  const char* what = "hivt_temporal_input_fwd";
+  HIVT_REQUIRE(T > 0 && N >= 0 && D > 0 && D % 4 == 0 && pm_stride >= T, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (N == 0) return HIVT_OK;
+  HIVT_REQUIRE(x && padding_mask && padding_token && cls_token && pos_embed && out && pad_code, HIVT_ERR_ARG,
+               "%s: null pointer", what);
+  HIVT_REQUIRE(al16(x) && al16(padding_token) && al16(cls_token) && al16(pos_embed) && al16(out), HIVT_ERR_ARG,
+               "%s: rows must start on 16-byte boundaries", what);
+  hipLaunchKernelGGL(temporal_input_fwd_kernel, dim3(grid_for((int64_t)(T + 1) * N * (D / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, new_id, padding_mask, pm_stride, padding_token, cls_token, pos_embed, T, N,
+                     D / 4, out, pad_code);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_gather_live_rows(const float* dy, const int32_t* rows, const int32_t* count, int32_t capacity,
+                                     int32_t D, float* dx, hivt_stream_t stream) {
+  const char* what = "hivt_gather_live_rows";
+  HIVT_REQUIRE(capacity >= 0 && D > 0 && D % 4 == 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (capacity == 0) return HIVT_OK;
+  HIVT_REQUIRE(dy && rows && count && dx && al16(dy) && al16(dx), HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(gather_live_rows_kernel, dim3(grid_for((int64_t)capacity * (D / 4))), dim3(256), 0,
+                     (hipStream_t)stream, dy, rows, count, capacity, D / 4, dx);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_decoder_output_fwd(const float* loc, int64_t loc_ld, const float* scale_raw, int64_t raw_ld, int64_t M,
+                                       int32_t H, int32_t F, float min_scale, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_decoder_output_fwd";
+  HIVT_REQUIRE(M >= 0 && H > 0 && (F <= 1 || M % F == 0), HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(loc && scale_raw && out && al8(loc) && al8(scale_raw) && al16(out) && loc_ld % 2 == 0 && raw_ld % 2 == 0,
+               HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(decoder_output_fwd_kernel, dim3(grid_for(M * H)), dim3(256), 0, (hipStream_t)stream, loc, loc_ld,
+                     scale_raw, raw_ld, M, H, F, min_scale, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_decoder_output_bwd(const float* d_out, const float* scale_raw, int64_t raw_ld, int64_t M, int32_t H,
+                                       int32_t F, float min_scale, float* d_loc, float* d_scale_raw,
+                                       hivt_stream_t stream) {
+  const char* what = "hivt_decoder_output_bwd";
+  HIVT_REQUIRE(M >= 0 && H > 0 && (F <= 1 || M % F == 0), HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (M == 0) return HIVT_OK;
+  HIVT_REQUIRE(d_out && scale_raw && d_loc && d_scale_raw && al16(d_out) && al8(scale_raw) && al8(d_loc) &&
+                   al8(d_scale_raw) && raw_ld % 2 == 0,
+               HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(decoder_output_bwd_kernel, dim3(grid_for(M * H)), dim3(256), 0, (hipStream_t)stream, d_out,
+                     scale_raw, raw_ld, M, H, F, min_scale, d_loc, d_scale_raw);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_select_mode_fwd(const float* y_hat, const int64_t* best_mode, int32_t F, int32_t N, int32_t H,
+                                    int32_t C, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_select_mode_fwd";
+  HIVT_REQUIRE(F > 0 && N >= 0 && H > 0 && C >= 2 && C % 2 == 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (N == 0) return HIVT_OK;
+  HIVT_REQUIRE(y_hat && best_mode && out && al8(y_hat) && al8(out), HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(select_mode_fwd_kernel, dim3(grid_for((int64_t)N * H)), dim3(256), 0, (hipStream_t)stream, y_hat,
+                     best_mode, F, N, H, C, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_select_mode_bwd(const float* g, const int64_t* best_mode, int32_t F, int32_t N, int32_t H, int32_t C,
+                                    float* d_y_hat, hivt_stream_t stream) {
+  const char* what = "hivt_select_mode_bwd";
+  HIVT_REQUIRE(F > 0 && N >= 0 && H > 0 && C >= 2 && C % 2 == 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  if (N == 0) return HIVT_OK;
+  HIVT_REQUIRE(g && best_mode && d_y_hat && al8(g) && al8(d_y_hat), HIVT_ERR_ARG, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(select_mode_bwd_kernel, dim3(grid_for((int64_t)N * H)), dim3(256), 0, (hipStream_t)stream, g,
+                     best_mode, F, N, H, C, d_y_hat);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_sum_padded_rows(const float* const* parts, const int32_t* widths, int32_t count, int64_t B,
+                                    int32_t W, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_sum_padded_rows";
+  HIVT_REQUIRE(count >= 1 && count <= 4 && B >= 0 && W > 0 && parts && widths, HIVT_ERR_ARG, "%s: 1..4 parts", what);
+  if (B == 0) return HIVT_OK;
+  HIVT_REQUIRE(out != nullptr, HIVT_ERR_ARG, "%s: out is null", what);
+  PaddedParts p{};
+  p.count = count;
+  for (int k = 0; k < count; ++k) {
+    HIVT_REQUIRE(parts[k] != nullptr && widths[k] >= 1 && widths[k] <= W, HIVT_ERR_ARG, "%s: part %d malformed", what, k);
+    p.part[k] = parts[k];
+    p.width[k] = widths[k];
+  }
+  hipLaunchKernelGGL(sum_padded_rows_kernel, dim3(grid_for(B * W)), dim3(256), 0, (hipStream_t)stream, p, B, W, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_category_table_fwd(const float* a, const float* b, const float* c, int32_t na, int32_t nb, int32_t nc,
+                                       int32_t D, float* out, hivt_stream_t stream) {
+  const char* what = "hivt_category_table_fwd";
+  HIVT_REQUIRE(na > 0 && nb > 0 && nc > 0 && D > 0 && (int64_t)na * nb * nc * D < (1 << 24), HIVT_ERR_ARG, "%s: bad sizes",
+               what);
+  HIVT_REQUIRE(a && b && c && out, HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(category_table_fwd_kernel, dim3(grid_for((int64_t)na * nb * nc * D)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, c, na, nb, nc, D, out);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}
+
+extern "C" int hivt_category_table_bwd(const float* g, int32_t na, int32_t nb, int32_t nc, int32_t D, float* da, float* db,
+                                       float* dc, hivt_stream_t stream) {
+  const char* what = "hivt_category_table_bwd";
+  HIVT_REQUIRE(na > 0 && nb > 0 && nc > 0 && D > 0 && (int64_t)na * nb * nc * D < (1 << 24), HIVT_ERR_ARG, "%s: bad sizes",
+               what);
+  HIVT_REQUIRE(g && da && db && dc, HIVT_ERR_ARG, "%s: null pointer", what);
+  hipLaunchKernelGGL(category_table_bwd_kernel, dim3(grid_for((int64_t)(na + nb + nc) * D)), dim3(256), 0,
+                     (hipStream_t)stream, g, na, nb, nc, D, da, db, dc);
+  HIVT_CHECK_LAUNCH(what);
+  return HIVT_OK;
+}

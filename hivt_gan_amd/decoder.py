@@ -15,9 +15,11 @@ from .embedding import init_weights
 
 def _run(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """``seq(x)`` for a stack of Linear [, LayerNorm [, ReLU]] groups, one fused launch per group on the GPU."""
-    if not x.is_cuda:
-        return seq(x)
     mods = list(seq)
+    if not x.is_cuda:
+        for mod in mods:
+            x = mod(x)
+        return x
     i = 0
     while i < len(mods):
         lin = mods[i]
@@ -53,8 +55,32 @@ class MLPDecoder(nn.Module):
                                 nn.Linear(hid, hid), nn.LayerNorm(hid), nn.ReLU(inplace=True), nn.Linear(hid, 1))
         self.apply(init_weights)
 
+    def _forward_fused(self, local_embed: torch.Tensor, global_embed: torch.Tensor
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The GPU route: no concatenated inputs (``ops.decoder_inputs``), the rows kept in the order they arrive in,
+        and the output tensor assembled by one launch (``ops.decoder_output``)."""
+        modes, n, d = global_embed.shape
+        # [F, N, D] as a transposed view of [N, F, D] (what the interaction module hands over): rows stay
+        # agent-major, which saves the copy into mode-major order and leaves pi [N, F] contiguous
+        agent_major = modes > 1 and global_embed.transpose(0, 1).is_contiguous()
+        g = global_embed.transpose(0, 1).reshape(n * modes, d) if agent_major else global_embed.reshape(modes * n, d)
+        out, pi_h = ops.decoder_inputs(g, local_embed, modes, agent_major, self.aggr_embed[0], self.aggr_embed[1],
+                                       self.pi[0], self.pi[1])
+        pi = _run(list(self.pi)[3:], pi_h)
+        pi = pi.view(n, modes) if agent_major else pi.view(modes, n).t()
+        loc = _run(self.loc, out)
+        if not self.uncertain:
+            loc = loc.view(n, modes, self.future_steps, 2).transpose(0, 1) if agent_major else \
+                loc.view(modes, n, self.future_steps, 2)
+            return loc, pi
+        return ops.decoder_output(loc, _run(self.scale, out), modes, agent_major, 0.05), pi
+
     def forward(self, local_embed: torch.Tensor, global_embed: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """local_embed [N, D], global_embed [F, N, D] -> (y_hat [F, N, H, 4 or 2], pi [N, F])."""
+        if (local_embed.is_cuda and local_embed.dtype == torch.float32 and self.input_size == self.hidden_size
+                and self.hidden_size <= 128 and self.hidden_size % 4 == 0 and global_embed.shape[0] == self.num_modes
+                and local_embed.numel() > 0):
+            return self._forward_fused(local_embed, global_embed)
         tiled = local_embed.expand(self.num_modes, *local_embed.shape)
         pi = _run(self.pi, torch.cat((tiled, global_embed), dim=-1)).squeeze(-1).t()
         out = _run(self.aggr_embed, torch.cat((global_embed, tiled), dim=-1))

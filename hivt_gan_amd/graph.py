@@ -45,7 +45,7 @@ def pack_inputs(batch: TemporalData) -> TemporalData:
         total += -(-t.numel() * t.element_size() // 256) * 256
     dev = batch[keys[0]].device
     arena = torch.empty(max(total, 256), dtype=torch.uint8, device=dev)
-    out = TemporalData(**{k: batch[k] for k in batch.keys() if k not in ("edge_plan", "_arena", "_arena_layout")})
+    out = TemporalData(**{k: batch[k] for k in batch.keys() if k not in ("edge_plan", "_prep", "_arena", "_arena_layout")})
     for k, off, shape, dtype in layout:
         n = batch[k].numel() * batch[k].element_size()
         view = arena[off:off + n].view(dtype).view(shape)
@@ -123,7 +123,7 @@ class GraphedStep:
         # in one copy
         self.static = pack_inputs(TemporalData(**{k: (example[k].clone() if torch.is_tensor(example[k]) else example[k])
                                                   for k in example.keys()
-                                                  if k not in ("edge_plan", "_arena", "_arena_layout")}))
+                                                  if k not in ("edge_plan", "_prep", "_arena", "_arena_layout")}))
         self._y = self.static["y"]
         dev = self._y.device
         self.device = dev

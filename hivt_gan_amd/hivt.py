@@ -28,6 +28,7 @@ from .global_interactor import GlobalInteractor
 from .local_encoder import LocalEncoder
 from .metrics import ValidationMetrics
 from .optim import FusedAdamW
+from .critics import multi_supported
 from .losses import (AdversarialDiscriminatorLoss, AdversarialGeneratorLoss, LaplaceNLLLoss,
                      SoftTargetCrossEntropyLoss, fused_supervised_losses, join_critic_streams)
 
@@ -130,7 +131,16 @@ class HiVT(nn.Module):
         """(y_hat [F, N, H, 4], pi [N, F]).  Like the reference, rotates ``data.y`` into each agent's
         frame IN PLACE on the batch object and stores ``rotate_mat`` on it (``models/hivt.py:151-169``):
         re-using one batch object for two forwards needs ``data.y`` restored in between."""
-        if self.rotate:
+        data["_prep"] = None
+        if self.rotate and ops.batch_prepare_supported(data, self.historical_steps) \
+                and int(data["padding_mask"].shape[1]) == self.historical_steps + self.future_steps:
+            # rotation matrices, rotated targets and histories, lane codes and the loss weights in one launch
+            prep = ops.batch_prepare(data, self.historical_steps)
+            if prep["y"] is not None:
+                data["y"] = prep["y"]
+            data["rotate_mat"] = prep["rotate_mat"]
+            data["_prep"] = prep
+        elif self.rotate:
             ang = data["rotate_angles"]
             sin, cos = torch.sin(ang), torch.cos(ang)
             rotate_mat = torch.stack([cos, -sin, sin, cos], dim=-1).view(-1, 2, 2)
@@ -276,11 +286,20 @@ class HiVT(nn.Module):
                                                self.gradient_clip_val, foreach=True)
             opt.step()
 
-        reg_loss, cls_loss, best_mode = self._supervised_losses(data, y_hat, pi)
-        logs: Dict[str, torch.Tensor] = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
+        packed = None
+        if y_hat.is_cuda and y_hat.dtype == torch.float32 and y_hat.shape[-1] == 4:
+            # the two supervised losses as one tensor, and (GAN step) the best mode's locations out of the same node
+            packed, best_mode, fake = ops.supervised_loss_packed(y_hat, pi, data["y"], data["padding_mask"],
+                                                                 self.historical_steps, want_best_traj=self.use_gan)
+            plain = packed.detach()
+            reg_loss, cls_loss = plain[0], plain[1]
+            logs: Dict[str, torch.Tensor] = {"reg_loss": reg_loss, "cls_loss": cls_loss}
+        else:
+            reg_loss, cls_loss, best_mode = self._supervised_losses(data, y_hat, pi)
+            logs = {"reg_loss": reg_loss.detach(), "cls_loss": cls_loss.detach()}
 
         if not self.use_gan:  # Case A, models/hivt.py:270-285
-            loss = reg_loss + cls_loss
+            loss = packed[0] + packed[1] if packed is not None else reg_loss + cls_loss
             opt_g.zero_grad(set_to_none=True)
             arm("generator")
             loss.backward()
@@ -288,10 +307,21 @@ class HiVT(nn.Module):
             logs["loss"] = loss.detach()
             return logs
 
-        real, fake, keep = self._real_fake(data, y_hat, best_mode)
+        prep = data.get("_prep")
+        if packed is not None:
+            real = data["y"]
+            if prep is not None:
+                keep, w, cnt = None, prep["keep_w"], prep["keep_count"]
+            else:
+                keep = (~data["padding_mask"][:, self.historical_steps:]).any(dim=1)
+                w = keep.to(real.dtype)
+                cnt = w.sum().clamp(min=1.0)
+        else:
+            real, fake, keep = self._real_fake(data, y_hat, best_mode)
+            w = cnt = None
         critic_params = self.critic_parameters()
         for _ in range(self.critic_steps):  # models/hivt.py:305-314
-            d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep)
+            d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep, w, cnt)
             opt_d.zero_grad(set_to_none=True)
             arm("critic")
             d_loss.backward()
@@ -303,8 +333,11 @@ class HiVT(nn.Module):
         for p in critic_params:
             p.requires_grad_(False)
         try:
-            g_adv, g_logs = self.g_loss_fn.forward_masked(self.critics, fake, keep)
-            g_total = reg_loss + cls_loss + g_adv
+            if packed is not None and len(self.critics) <= 4 and multi_supported(self.critics.values(), fake):
+                g_total, g_adv, g_logs = self.g_loss_fn.total_masked(self.critics, fake, packed, w, cnt)
+            else:
+                g_adv, g_logs = self.g_loss_fn.forward_masked(self.critics, fake, keep, w, cnt)
+                g_total = (packed[0] + packed[1] if packed is not None else reg_loss + cls_loss) + g_adv
             opt_g.zero_grad(set_to_none=True)
             arm("generator")
             g_total.backward()

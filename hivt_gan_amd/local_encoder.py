@@ -36,7 +36,7 @@ class EdgePlan:
     lane_actor: EdgeSet    # lane -> actor within the radius        (local_encoder.py:80)
     interaction: EdgeSet   # agents valid at the last history step  (global_interactor.py:48-50)
     overflow: Optional[torch.Tensor] = None  # device bool: a filtered list exceeded its fixed capacity
-    counts: Optional[torch.Tensor] = None    # device int32 [3]: unclamped live counts (fixed-capacity mode)
+    counts: Optional[tuple] = None           # three device int32 scalars: unclamped live counts (fixed-capacity mode)
     # the (step, agent) nodes of the agent-agent stage that are not padded, packed: the stage's output at a padded
     # node is replaced by the padding token before anything reads it (local_encoder.py:230), so the stage is
     # evaluated for the other nodes only
@@ -104,11 +104,16 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
     caps = data.get("edge_capacity")
     if from_pairs is None:
         from_pairs = bool(data.get("all_pairs", False)) and "scene_range" in data
-    la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
-    # nodes (t, n) of the agent-agent stage that are not padded, t-major
-    valid = ~data["padding_mask"][:, :T].t().reshape(-1) if (PACK_AGENT_ROWS and n > 0) else None
+    # nodes (t, n) of the agent-agent stage that are not padded, t-major (the fixed-capacity all-pairs route reads
+    # the mask itself and only needs to know that the rows are packed)
+    pack = PACK_AGENT_ROWS and n > 0
+    fused_rows = pack and caps is not None and from_pairs and data["padding_mask"].is_cuda
+    valid = None
+    if pack:
+        valid = True if fused_rows else ~data["padding_mask"][:, :T].t().reshape(-1)
     # (read back with the edge counts when no capacities are given; a fixed-capacity plan never needs it)
     live_rows = valid.sum(dtype=torch.int32).view(1) if (valid is not None and caps is None) else None
+    la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
     row_cap = min(int(caps[3]), T * n) if (caps is not None and len(caps) > 3) else T * n
     if from_pairs:
         e0 = int(data["edge_index"].shape[1])
@@ -124,15 +129,21 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
             rows = ops.row_subset(valid, None, sets[0].rowptr, int(counts[3])) if valid is not None else None
             return EdgePlan(*sets, aa_rows=rows)
         c_la = min(int(caps[1]), int(la[0].shape[0]))
+        if valid is not None:
+            # every consumer of a fixed-capacity list bounds the device count by the list's length itself, so the
+            # counts go down as they are; the packed agent-agent rows and the overflow flag of all four capacities
+            # come out of one call
+            sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4]),
+                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3]),
+                    EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4])]
+            rows = ops.row_subset_fixed(data["padding_mask"], T, row_cap, sets[0].rowptr, (aa[4], la[3], gi[4]),
+                                        (pair_caps[0], c_la, pair_caps[1]))
+            return EdgePlan(*sets, overflow=rows.overflow, counts=(aa[4], la[3], gi[4]), aa_rows=rows)
         sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4].clamp(max=pair_caps[0])),
                 ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3].clamp(max=c_la)),
                 EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4].clamp(max=pair_caps[1]))]
-        counts = torch.cat([aa[4], la[3], gi[4]])
         overflow = (aa[4] > pair_caps[0]) | (la[3] > c_la) | (gi[4] > pair_caps[1])
-        rows = ops.row_subset(valid, row_cap, sets[0].rowptr) if valid is not None else None
-        if rows is not None:
-            overflow = overflow | rows.overflow
-        return EdgePlan(*sets, overflow=overflow.view(()), counts=counts, aa_rows=rows)
+        return EdgePlan(*sets, overflow=overflow.view(()), counts=(aa[4], la[3], gi[4]), aa_rows=None)
     aa = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], 0, T, local_radius)
     gi = ops.edges_temporal(data["edge_index"], data["padding_mask"], data["positions"], T - 1, 1, None)
     shapes = ((T * n, T * n), (num_lanes, n), (n, n))
@@ -149,11 +160,10 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
         sets.append(ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd, count=lst[3].clamp(max=c)))
         over = lst[3] > c
         overflow = over if overflow is None else overflow | over
-    counts = torch.cat([aa[3], la[3], gi[3]])
     rows = ops.row_subset(valid, row_cap, sets[0].rowptr) if valid is not None else None
     if rows is not None:
         overflow = overflow | rows.overflow
-    return EdgePlan(*sets, overflow=overflow.view(()), counts=counts, aa_rows=rows)
+    return EdgePlan(*sets, overflow=overflow.view(()), counts=(aa[3], la[3], gi[3]), aa_rows=rows)
 
 
 def _edge_set_from_coo(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_src: int, num_dst: int) -> EdgeSet:
@@ -262,18 +272,28 @@ class AAEncoder(_EdgeAttentionBase):
 
     def forward(self, x: torch.Tensor, t: Optional[int], edge_index: Optional[torch.Tensor],
                 edge_attr: Optional[torch.Tensor], bos_mask: torch.Tensor, rotate_mat: Optional[torch.Tensor] = None,
-                size=None, edges: Optional[EdgeSet] = None, rows: Optional[ops.RowSubset] = None) -> torch.Tensor:
+                size=None, edges: Optional[EdgeSet] = None, rows: Optional[ops.RowSubset] = None,
+                x_rotated: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``parallel`` modules (or ``t is None``) take x [T*N, 2], bos_mask [N, T] and node ids
         ``t*N + n``; otherwise x [N, 2], an integer ``t`` and bos_mask [N].  ``edges`` may carry the
         already grouped edge set instead of ``edge_index`` / ``edge_attr``.  With ``rows`` (batched form, GPU) the
         stage is evaluated for that subset of the T*N nodes only and the result holds its packed rows
-        [rows.capacity, D]; nodes outside the subset must own no edges."""
+        [rows.capacity, D]; nodes outside the subset must own no edges.  ``x_rotated`` (with ``rows``): ``x`` already
+        rotated into the agents' frames, [T*N, 2]."""
         T = self.historical_steps
         batched = self.parallel or t is None
         rowptr = None
         if rows is not None and not (batched and edges is not None and rows.rowptr is not None):
             raise ValueError("a row subset goes with the batched form and a grouped edge set")
-        if batched:
+        if batched and rows is not None and x_rotated is not None and self.embed_dim % 4 == 0:
+            # packed nodes from prepared rows: one launch for the inputs of the centre embedding and the
+            # begin-of-sequence codes, one for the substitution of the tokens
+            n = x.shape[0] // T
+            xc, code = ops.center_rows(x_rotated, bos_mask, rows.rows, n, T)
+            center = ops.rows_put_tokens(self.center_embed(xc), code, self.bos_token)
+            rowptr = rows.rowptr
+            rot_mod = n
+        elif batched:
             n = x.shape[0] // T
             xv = x.view(T, n, -1)
             if rotate_mat is not None:  # row vector times the agent's 2x2, written out (no batched GEMM)
@@ -331,12 +351,15 @@ class ALEncoder(_EdgeAttentionBase):
     def forward(self, x: Tuple[torch.Tensor, torch.Tensor], edge_index: Optional[torch.Tensor],
                 edge_attr: Optional[torch.Tensor], is_intersections: torch.Tensor, turn_directions: torch.Tensor,
                 traffic_controls: torch.Tensor, rotate_mat: Optional[torch.Tensor] = None, size=None,
-                edges: Optional[EdgeSet] = None) -> torch.Tensor:
+                edges: Optional[EdgeSet] = None, lane_code: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``lane_code`` (optional, int32 [L]): ``(is_intersections * 3 + turn_directions) * 2 + traffic_controls``
+        if the caller has it already."""
         x_lane, x_actor = x
         if edges is None:
             edges = _edge_set_from_coo(edge_index, edge_attr, x_lane.shape[0], x_actor.shape[0])
         # one code per lane for the three categorical attributes, one table row per code
-        code = (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
+        code = lane_code if lane_code is not None else \
+            (is_intersections.long() * 3 + turn_directions.long()) * 2 + traffic_controls.long()
         normed, x_actor = ops.layer_norm_residual(x_actor, self.norm1)
         x_actor = self._mha_block(normed, x_lane, edges, code, rotate_mat, residual=x_actor)
         return _pre_norm_ffn(x_actor, self.norm2, self.mlp)
@@ -345,8 +368,11 @@ class ALEncoder(_EdgeAttentionBase):
                    rotate_mat: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         feat, src_csr, _dst = ops.edge_gather_rotate(x_lane, edges.coo_attr, rotate_mat, edges.coo_src, edges.coo_dst,
                                                      edges.perm, x_actor.shape[0], edges.count)
-        table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
-                 + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
+        if x_actor.is_cuda and x_actor.dtype == torch.float32:
+            table = ops.category_table(self.is_intersection_embed, self.turn_direction_embed, self.traffic_control_embed)
+        else:
+            table = ((self.is_intersection_embed.view(2, 1, 1, -1) + self.turn_direction_embed.view(1, 3, 1, -1))
+                     + self.traffic_control_embed.view(1, 1, 2, -1)).reshape(12, -1)
         # the 12-row table is added per edge inside the embedding's second launch (row picked by the
         # lane's code); its gradient is a per-code sum of rows, not E*D contended atomic adds
         code_per_edge = lane_code.to(torch.int32).index_select(0, src_csr)
@@ -511,7 +537,13 @@ class TemporalEncoder(nn.Module):
     def forward(self, x: torch.Tensor, padding_mask: torch.Tensor, rows: Optional[ops.RowSubset] = None
                 ) -> torch.Tensor:
         """x [T, N, D]; or, with ``rows`` (the unpadded (step, agent) nodes, packed), x [rows.capacity, D]."""
-        if rows is not None:
+        steps = self.padding_token.shape[0]
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 128 and steps + 1 <= 32 \
+                and x.numel() > 0:
+            # tokens, packed rows and positional rows in one launch
+            x = ops.temporal_input(x, rows, padding_mask, self.padding_token.squeeze(1), self.cls_token.view(-1),
+                                   self.pos_embed.squeeze(1))
+        elif rows is not None:
             x = ops.expand_rows_with_tokens(x, rows, padding_mask.t(), self.padding_token.squeeze(1))
             x = ops.append_token_add_steps(x, self.cls_token.view(-1), self.pos_embed.squeeze(1))
         elif ops.step_tokens_supported(x, x.shape[0] + 1):
@@ -552,17 +584,19 @@ class LocalEncoder(nn.Module):
         if plan is None:
             plan = build_edge_plan(data, T, self.local_radius)
             data["edge_plan"] = plan
-        x_all = data["x"][:, :T].transpose(0, 1).reshape(T * n, -1)
+        prep = data.get("_prep")
+        x_all = prep["x_steps"] if prep is not None else data["x"][:, :T].transpose(0, 1).reshape(T * n, -1)
         rows = plan.aa_rows
         if rows is not None and not (x_all.is_cuda and self.aa_encoder.embed_dim <= 128 and T + 1 <= 32):
             rows = None
         out = self.aa_encoder(x=x_all, t=None, edge_index=None, edge_attr=None, bos_mask=data["bos_mask"],
-                              rotate_mat=data["rotate_mat"], edges=plan.agent_agent, rows=rows)
+                              rotate_mat=data["rotate_mat"], edges=plan.agent_agent, rows=rows,
+                              x_rotated=prep["x_rot"] if prep is not None else None)
         if rows is None:
             out = out.view(T, n, -1)
         out = self.temporal_encoder(x=out, padding_mask=data["padding_mask"][:, :T], rows=rows)
         out = self.al_encoder(x=(data["lane_vectors"], out), edge_index=None, edge_attr=None,
                               is_intersections=data["is_intersections"], turn_directions=data["turn_directions"],
                               traffic_controls=data["traffic_controls"], rotate_mat=data["rotate_mat"],
-                              edges=plan.lane_actor)
+                              edges=plan.lane_actor, lane_code=prep["lane_code"] if prep is not None else None)
         return out

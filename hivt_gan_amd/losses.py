@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -125,12 +125,14 @@ class AdversarialDiscriminatorLoss(nn.Module):
             logs[f"r1_{name}"] = r1.detach()
         return total, logs
 
-    def forward_masked(self, critics: dict, real: torch.Tensor, fake: torch.Tensor, keep: torch.Tensor):
+    def forward_masked(self, critics: dict, real: torch.Tensor, fake: torch.Tensor, keep: Optional[torch.Tensor],
+                       weights: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
         """Same value as ``forward`` on ``real[keep]`` / ``fake[keep]`` sliced to each critic's horizon,
         computed on all rows with ``keep`` as weights (no data-dependent shapes, no host sync).
-        Valid because every term is a per-sample mean and the critics act row-wise."""
-        w = keep.to(real.dtype)
-        cnt = w.sum().clamp(min=1.0)
+        Valid because every term is a per-sample mean and the critics act row-wise.  ``weights`` / ``count``: the
+        keep mask as floats and the number of kept rows (at least 1), if the caller has them already."""
+        w = weights if weights is not None else keep.to(real.dtype)
+        cnt = count if count is not None else w.sum().clamp(min=1.0)
         real, fake = real.detach(), fake.detach()
 
         def one(name, critic):
@@ -149,6 +151,13 @@ class AdversarialDiscriminatorLoss(nn.Module):
             # every critic on the real and on the generated rows in one library call (their launches are shared)
             members = list(critics.values())
             outs = scores_multi([(c, real, True) for c in members] + [(c, fake, False) for c in members])
+            if len(members) <= 4:  # the scales' terms and their sum in one launch
+                total, parts = ops.hinge_r1_multi([(outs[i][0], outs[i][1], outs[len(members) + i])
+                                                   for i in range(len(members))], w, cnt, self.lambda_r1)
+                for i, name in enumerate(critics):
+                    logs[f"d_loss_{name}"] = parts[2 * i]
+                    logs[f"r1_{name}"] = parts[2 * i + 1]
+                return total, logs
             terms = [ops.hinge_r1_loss(outs[i][0], outs[i][1], outs[len(members) + i], w, cnt, self.lambda_r1)
                      for i in range(len(members))]
         else:
@@ -175,9 +184,21 @@ class AdversarialGeneratorLoss(nn.Module):
             logs[f"g_loss_{name}"] = g.detach()
         return self.lambda_adv * total, logs
 
-    def forward_masked(self, critics: dict, fake: torch.Tensor, keep: torch.Tensor):
-        w = keep.to(fake.dtype)
-        cnt = w.sum().clamp(min=1.0)
+    def total_masked(self, critics: dict, fake: torch.Tensor, supervised: torch.Tensor, weights: torch.Tensor,
+                     count: torch.Tensor):
+        """``(g_total, g_adv, logs)`` with ``g_total = (supervised[0] + supervised[1]) + g_adv``
+        (``models/hivt.py:317-324``): the critics' passes in one library call and the objective with all of its
+        parts in one launch.  ``supervised`` = (regression, classification) loss as one tensor [2]; ``weights`` /
+        ``count`` as in ``forward_masked``.  Needs ``multi_supported`` critics, at most four."""
+        outs = scores_multi([(c, fake, False) for c in critics.values()])
+        total, parts = ops.generator_total(supervised, outs, weights, count, self.lambda_adv)
+        logs = {f"g_loss_{name}": parts[1 + i] for i, name in enumerate(critics)}
+        return total, parts[0], logs
+
+    def forward_masked(self, critics: dict, fake: torch.Tensor, keep: Optional[torch.Tensor],
+                       weights: Optional[torch.Tensor] = None, count: Optional[torch.Tensor] = None):
+        w = weights if weights is not None else keep.to(fake.dtype)
+        cnt = count if count is not None else w.sum().clamp(min=1.0)
         total, logs = 0.0, {}
         def one(_, critic):
             scores = critic(fake)

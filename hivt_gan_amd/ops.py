@@ -505,7 +505,7 @@ def gated_update(agg: torch.Tensor, ih: torch.Tensor, hh_self: torch.Tensor) -> 
 class _SupervisedLoss(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, y_hat, pi, y, padding_mask, t_hist):
+    def forward(ctx, y_hat, pi, y, padding_mask, t_hist, want_best_traj):
         _need_gpu(y_hat, pi, y, padding_mask)
         f, n, hf, ch = y_hat.shape
         if ch != 4 or pi.shape != (n, f) or y.shape != (n, hf, 2):
@@ -521,29 +521,48 @@ class _SupervisedLoss(torch.autograd.Function):
         ws = _workspace(_lib.query("hivt_laplace_workspace_bytes", n), dev)
         _lib.call("hivt_laplace_minmode_fwd", _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), int(t_hist), f, n, hf,
                   _p(losses), _p(best), _p(soft), _p(stats), _p(ws), ws.numel(), _stream(y_hat))
+        traj = None
+        if want_best_traj:  # the best mode's locations (models/hivt.py:221-224), cut out next to the argmin
+            traj = torch.empty(n, hf, 2, dtype=torch.float32, device=dev)
+            _lib.call("hivt_select_mode_fwd", _p(y_hat), _p(best), f, n, hf, 4, _p(traj), _stream(y_hat))
         ctx.save_for_backward(y_hat, pi, y, pm, best, soft, stats)
         ctx.t_hist = int(t_hist)
         ctx.mark_non_differentiable(best)
-        return losses, best
+        ctx.set_materialize_grads(False)
+        return losses, best, traj
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_losses, _g_best):
+    def backward(ctx, g_losses, _g_best, g_traj):
         y_hat, pi, y, pm, best, soft, stats = ctx.saved_tensors
         f, n, hf, _ = y_hat.shape
-        g = g_losses.contiguous().float()
+        g = g_losses.contiguous().float() if g_losses is not None else \
+            torch.zeros(2, dtype=torch.float32, device=y_hat.device)
         d_y_hat = torch.empty_like(y_hat)
         d_pi = torch.empty_like(pi)
         _lib.call("hivt_laplace_minmode_bwd", _p(g), _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), ctx.t_hist, f, n,
                   hf, _p(best), _p(soft), _p(stats), _p(d_y_hat), _p(d_pi), _stream(y_hat))
-        return d_y_hat, d_pi, None, None, None
+        if g_traj is not None:  # added where the best mode's locations lie
+            g_traj = g_traj.contiguous()
+            _lib.call("hivt_select_mode_bwd", _p(g_traj), _p(best), f, n, hf, 4, _p(d_y_hat), _stream(y_hat))
+        return d_y_hat, d_pi, None, None, None, None
 
 
 def supervised_loss(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
                     historical_steps: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(reg_loss, cls_loss, best_mode) of the best-of-F Laplace NLL + soft-target CE, without host sync."""
-    losses, best = _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps)
+    losses, best, _ = _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps, False)
     return losses[0], losses[1], best
+
+
+def supervised_loss_packed(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
+                           historical_steps: int, want_best_traj: bool = True
+                           ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """``(losses [2] = (reg_loss, cls_loss), best_mode [N], best_traj [N, H, 2] or None)``: the same losses as one
+    tensor (consumers that take it whole save the two select nodes and their gradient sums) plus the best mode's
+    predicted locations ``y_hat[best_mode, arange(N), :, :2]`` (``models/hivt.py:221-224``), whose gradient is added
+    inside this node's backward instead of through an index node."""
+    return _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps, bool(want_best_traj))
 
 
 # --------------------------------------------------------------------------------------------
@@ -639,8 +658,16 @@ def _launch_wgrad_group(flat, count: int, dev) -> None:
 # its chunks: all latency for layers of a few thousand rows, ramp-up and partial-sum traffic for long ones) are
 # collected while the backward pass runs and issued together when it ends (a callback of the autograd engine),
 # a few launches for all of them.  The operands stay alive until then.
-# The gradient tensors handed to autograd exist from the start and are filled by that call; nothing may read
-# a parameter's ``.grad`` from a hook before the pass has ended.
+#
+# Contract.  The gradient tensors handed to autograd exist from the start and are FILLED by that call, so autograd
+# must do nothing with them but adopt them as the parameters' ``.grad``.  A product is therefore deferred only if,
+# when its node runs, every parameter of the node is a leaf whose ``.grad`` is None and which carries no hooks
+# (a populated ``.grad`` -- gradient accumulation, ``zero_grad(set_to_none=False)`` -- would have the unfilled
+# buffer added to it; such products run on the spot).  What cannot be seen from inside a node -- one parameter
+# feeding two nodes of a graph, ``retain_graph`` replays, ``create_graph=True`` -- is checked when the queue is
+# issued: every buffer must by then BE the ``.grad`` of one of its node's parameters, otherwise the pass raises
+# instead of training on a sum that contains an unfilled buffer.  Nothing may read a parameter's ``.grad`` from a
+# hook before the pass has ended.
 _deferred: Optional[list] = None
 
 
@@ -663,53 +690,88 @@ class deferred_weight_grads:
         return False
 
 
+def _check_adopted(entries) -> None:
+    """Every deferred gradient buffer must have become the ``.grad`` of one of its node's parameters."""
+    for addresses, params in entries:
+        grads = {p.grad.data_ptr() for p in params if p.grad is not None}
+        # (views of one buffer -- the two halves of a pair of layers -- are adopted as views: same addresses)
+        for a in addresses:
+            if a and a not in grads:
+                raise RuntimeError(
+                    "deferred_weight_grads(): a weight gradient that was queued for the end of the backward pass was "
+                    "not adopted as its parameter's .grad (a parameter used by two nodes of one graph, a tensor hook, "
+                    "retain_grad or create_graph): its buffer was read before it was filled.  Run this backward pass "
+                    "outside deferred_weight_grads() (GanTrainer.defer_weight_grads = False)")
+
+
 def flush_weight_grads() -> None:
     """Issues the collected weight gradients (runs by itself at the end of every backward pass)."""
     rows = _deferred_rows
+    checks = []
     if rows:
         flat, keep, dev = [], [], rows[0][1]
-        for item, _, part in rows:
+        for item, _, part, check in rows:
             flat += item
             keep.append(part)
+            checks.append(check)
         count = len(rows)
         del rows[:]
         _lib.call("hivt_reduce_rows_group", (ctypes.c_int64 * len(flat))(*flat), count,
                   torch._C._cuda_getCurrentRawStream(dev.index))
         del keep
     queue = _deferred
-    if not queue:
-        return
-    flat, keep, dev = [], [], queue[0][1]
-    for item, _, tensors in queue:
-        flat += item
-        keep.append(tensors)
-    count = len(queue)
-    del queue[:]
-    _launch_wgrad_group(flat, count, dev)
-    del keep  # the operands stayed alive until the call that reads them was issued
+    if queue:
+        flat, keep, dev = [], [], queue[0][1]
+        for item, _, tensors, check in queue:
+            flat += item
+            keep.append(tensors)
+            checks.append(check)
+        count = len(queue)
+        del queue[:]
+        _launch_wgrad_group(flat, count, dev)
+        del keep  # the operands stayed alive until the call that reads them was issued
+    _check_adopted([c for c in checks if c is not None])
 
 
-def _all_leaves(*tensors) -> bool:
-    """True if every given tensor is a leaf of the autograd graph (a parameter, not a slice or a concatenation
-    of parameters): only then does nothing but the optimizer read its gradient."""
-    return all(t is None or t.is_leaf for t in tensors)
+def _all_leaves(*tensors):
+    """The given parameters as a tuple if every one of them is a leaf of the autograd graph (a parameter, not a
+    slice or a concatenation of parameters: only then does nothing but the optimizer read its gradient), else
+    None.  (None entries -- a layer without a bias -- are skipped.)"""
+    params = tuple(t for t in tensors if t is not None)
+    return params if all(t.is_leaf for t in params) else None
+
+
+def _may_defer(leaves) -> bool:
+    """Whether a product whose results go to the leaf parameters ``leaves`` may be deferred now: inside
+    ``deferred_weight_grads()``, every parameter without a gradient and without hooks."""
+    if not leaves or _deferred is None:
+        return False
+    for p in leaves:
+        if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _schedule_flush() -> None:
+    if not _deferred and not _deferred_rows:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
 
 
 def _weight_grad(g: torch.Tensor, g_ld: int, x: torch.Tensor, x_ld: int, m: int, n: int, k: int, dev,
-                 bias: bool = True, leaves: bool = False):
+                 bias: bool = True, leaves=None):
     """``(dW [n, k], db [n] or None)`` of ``y = x W^T + b`` from ``g = dL/dy`` [m, n] (fp32, or bfloat16 while
-    ``_half_gradients()``) and ``x`` [m, k].  ``leaves``: weight and bias are leaves of the graph, so the product
-    may be deferred."""
+    ``_half_gradients()``) and ``x`` [m, k].  ``leaves``: the leaf parameters the results go to (``_all_leaves``),
+    which allows the product to be deferred."""
     half = g.dtype == torch.bfloat16
     dw = torch.empty(n, k, dtype=torch.float32, device=dev)
     db = torch.empty(n, dtype=torch.float32, device=dev) if bias else None
-    if leaves and _deferred is not None and m > 0:
-        if not _deferred and not _deferred_rows:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+    if m > 0 and _may_defer(leaves):
+        _schedule_flush()
         # addresses, not tensors, of the results: autograd takes a gradient over only while it holds the one
         # reference to it
         _deferred.append(([g.data_ptr(), g_ld, x.data_ptr(), x_ld, m, n, k, dw.data_ptr(),
-                           db.data_ptr() if bias else 0, 4 if half else 0], dev, (g, x)))
+                           db.data_ptr() if bias else 0, 4 if half else 0], dev, (g, x),
+                          ((dw.data_ptr(), db.data_ptr() if bias else 0), leaves)))
         return dw, db
     ws = _workspace(_lib.query("hivt_linear_wgrad_workspace_bytes", m, n, k), dev)
     if half:
@@ -732,15 +794,14 @@ def _ln_backward(dy2, z, z_ld, stats, gamma, beta, relu: int, m: int, n: int, ad
     dbeta = torch.empty(n, dtype=torch.float32, device=dev)
     add_ld = add2.stride(0) if add2 is not None else 0
     name = "hivt_ln_bwd_half" if dz.dtype == torch.bfloat16 else "hivt_ln_bwd"
-    if leaves and _deferred is not None and m > 0:
+    if m > 0 and _may_defer(leaves):
         rows = _lib.query("hivt_ln_bwd_partial_rows", m)
         part = torch.empty(_lib.query("hivt_ln_bwd_workspace_bytes", m, n) // 4, dtype=torch.float32, device=dev)
         _lib.call(name, _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
                   _p(add2), add_ld, _p(dz), dz.stride(0), None, None, _p(part), part.numel() * 4, stream)
-        if not _deferred and not _deferred_rows:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+        _schedule_flush()
         _deferred_rows.append(([part.data_ptr(), rows, 2 * n, 2 * n, dgamma.data_ptr(), n, dbeta.data_ptr(), 0], dev,
-                               part))
+                               part, ((dgamma.data_ptr(), dbeta.data_ptr()), leaves)))
         return dgamma, dbeta
     ws = _workspace(_lib.query("hivt_ln_bwd_workspace_bytes", m, n), dev)
     _lib.call(name, _p(dy2), dy2.stride(0), _p(z), z_ld, _p(stats), _p(gamma), _p(beta), int(relu), m, n,
@@ -796,7 +857,7 @@ class _FusedLinear(torch.autograd.Function):
         ctx.res_leaf = residual is not None and residual.is_leaf
         ctx.add_leaf = add is not None and add.is_leaf
         ctx.param_leaves = _all_leaves(weight, bias)
-        ctx.norm_leaves = ln and _all_leaves(gamma, beta)
+        ctx.norm_leaves = _all_leaves(gamma, beta) if ln else None
         return y.view(*lead, n)
 
     @staticmethod
@@ -1392,30 +1453,48 @@ def critic_scores(x: torch.Tensor, weights, biases, neg_slope: float, dropout_p:
     return _Critic.apply(x, cfg, *params)
 
 
+def _critic_chainable(widths_list, layers: int, b: int, x2: torch.Tensor) -> bool:
+    """Whether the library carries a pass through its layer-chain kernel (the route on which passes of one critic
+    may share their gradient arrays): the conditions of the C side, restated."""
+    return (layers <= 4 and b > 0 and all(w % 4 == 0 for w in widths_list) and x2.stride(0) % 4 == 0
+            and x2.data_ptr() % 16 == 0)
+
+
 class _CriticsMulti(torch.autograd.Function):
     """Several critic passes (all critics, real and generated trajectories) per library call: forward and
-    backward are one call each, and the passes share their launches.  ``plan`` lists per pass ``(layers + 1,
-    with_r1, seed)``; the tensors follow as ``x, w_1, b_1, .., w_o, b_o`` per pass.  Outputs per pass: scores
-    [B] and, with ``with_r1``, ``||d score / d x||^2`` [B]."""
+    backward are one call each, and the passes share their launches.  ``plan = (inputs, critics, passes)``:
+    ``inputs`` input tensors come first, then per critic (``critics[c]`` = its number of linear layers) ``w_1, b_1,
+    .., w_o, b_o``; ``passes`` lists ``(input, critic, with_r1, seed)``.  A pass reads the first ``w_1.shape[1]``
+    columns of its input's flattened rows.  Outputs per pass: scores [B] and, with ``with_r1``,
+    ``||d score / d x||^2`` [B].  In backward the passes of one critic write ONE set of parameter gradients (their
+    sum) and the passes over one input ONE input gradient."""
 
     @staticmethod
     def forward(ctx, cfg, plan, *tensors):
         neg_slope, dropout_p = cfg
-        passes, table, keep, outs = [], [], [], []
-        at = 0
-        for n_lin, with_r1, seed in plan:
-            x = tensors[at]
-            params = tensors[at + 1:at + 1 + 2 * n_lin]
-            at += 1 + 2 * n_lin
-            weights = [p.contiguous() for p in params[0::2]]
-            biases = [p.contiguous() for p in params[1::2]]
-            _need_gpu(x, *weights)
-            layers = n_lin - 1
+        n_inputs, critics, pass_plan = plan
+        xs = tensors[:n_inputs]
+        params, at = [], n_inputs
+        for n_lin in critics:
+            group = tensors[at:at + 2 * n_lin]
+            at += 2 * n_lin
+            params.append(([p.contiguous() for p in group[0::2]], [p.contiguous() for p in group[1::2]]))
+        x2s = []
+        for x in xs:
             x2 = x.reshape(x.shape[0], -1)
             if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]) or x2.dtype != torch.float32:
                 x2 = x2.contiguous().float()
+            x2s.append(x2)
+        passes, table, keep, outs = [], [], [], []
+        for x_idx, c_idx, with_r1, seed in pass_plan:
+            weights, biases = params[c_idx]
+            x2 = x2s[x_idx]
+            _need_gpu(x2, *weights)
+            layers = len(weights) - 1
             b = x2.shape[0]
-            widths_list = [x2.shape[1]] + [w.shape[0] for w in weights[:-1]]
+            widths_list = [weights[0].shape[1]] + [w.shape[0] for w in weights[:-1]]
+            if widths_list[0] > x2.shape[1]:
+                raise ValueError("critic input rows are narrower than the first layer")
             for l, w in enumerate(weights[:-1]):
                 if w.shape[1] != widths_list[l]:
                     raise ValueError("critic layer widths do not chain")
@@ -1432,23 +1511,23 @@ class _CriticsMulti(torch.autograd.Function):
                       ctypes.addressof(w_ptrs), ctypes.addressof(b_ptrs), int(seed), int(with_r1), saved.data_ptr(),
                       scores.data_ptr(), gn2.data_ptr() if with_r1 else 0]
             keep.append((widths, w_ptrs, b_ptrs))
-            passes.append((x2, saved, weights, widths_list, tuple(x.shape), [tuple(t.shape) for t in biases], bool(with_r1)))
+            passes.append((saved, widths_list, bool(with_r1)))
             outs.append(scores)
             if with_r1:
                 outs.append(gn2)
-        dev = passes[0][0].device
+        dev = x2s[0].device
         arr = (ctypes.c_int64 * len(table))(*table)
         _lib.call("hivt_critics_fwd", arr, len(passes), float(neg_slope), float(dropout_p), _seed_ptr(dropout_p),
                   torch._C._cuda_getCurrentRawStream(dev.index))
         del keep
-        flat = []
-        for x2, saved, weights, *_ in passes:
-            flat += [x2, saved, *weights]
+        flat = list(x2s) + [saved for saved, _, _ in passes]
+        for weights, _ in params:
+            flat += weights
         ctx.save_for_backward(*flat)
-        ctx.meta = [(len(weights), widths_list, x_shape, bias_shapes, with_r1)
-                    for _, _, weights, widths_list, x_shape, bias_shapes, with_r1 in passes]
+        ctx.meta = ([tuple(x.shape) for x in xs], [(len(w), [tuple(t.shape) for t in bs]) for w, bs in params],
+                    [(x_idx, c_idx, widths_list, with_r1)
+                     for (x_idx, c_idx, _, _), (_, widths_list, with_r1) in zip(pass_plan, passes)])
         ctx.cfg = (float(neg_slope), float(dropout_p))
-        ctx.plan = plan
         ctx.set_materialize_grads(False)
         return tuple(outs)
 
@@ -1456,55 +1535,106 @@ class _CriticsMulti(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, *gouts):
         neg_slope, dropout_p = ctx.cfg
+        x_shapes, critic_meta, pass_meta = ctx.meta
         saved_tensors = ctx.saved_tensors
-        table, keep, results = [], [], []
-        at, out_at, in_at = 0, 0, 2  # positions in saved tensors, grad outputs, forward inputs (after cfg, plan)
-        dev = saved_tensors[0].device
-        for n_lin, widths_list, x_shape, bias_shapes, with_r1 in ctx.meta:
-            x2, saved = saved_tensors[at], saved_tensors[at + 1]
-            weights = list(saved_tensors[at + 2:at + 2 + n_lin])
-            at += 2 + n_lin
-            g_scores = gouts[out_at]
-            g_norm2 = gouts[out_at + 1] if with_r1 else None
+        n_inputs, n_passes = len(x_shapes), len(pass_meta)
+        x2s = saved_tensors[:n_inputs]
+        saveds = saved_tensors[n_inputs:n_inputs + n_passes]
+        weights_of, at = [], n_inputs + n_passes
+        for n_lin, _ in critic_meta:
+            weights_of.append(list(saved_tensors[at:at + n_lin]))
+            at += n_lin
+        dev = x2s[0].device
+        # which inputs of forward want a gradient (after cfg, plan: the inputs, then every critic's parameters)
+        need_x = [ctx.needs_input_grad[2 + i] for i in range(n_inputs)]
+        need_params, in_at = [], 2 + n_inputs
+        for n_lin, _ in critic_meta:
+            need_params.append(any(ctx.needs_input_grad[in_at:in_at + 2 * n_lin]))
+            in_at += 2 * n_lin
+        # incoming gradients per pass
+        grads_in, out_at = [], 0
+        for _, _, _, with_r1 in pass_meta:
+            grads_in.append((gouts[out_at], gouts[out_at + 1] if with_r1 else None))
             out_at += 2 if with_r1 else 1
-            need_x = ctx.needs_input_grad[in_at]
-            need_params = any(ctx.needs_input_grad[in_at + 1:in_at + 1 + 2 * n_lin])
-            in_at += 1 + 2 * n_lin
-            layers = n_lin - 1
+        # one set of parameter gradients per critic, shared by its passes when the library can sum them itself
+        param_grads = [None] * len(critic_meta)   # (dws, dbs, dw_ptrs, db_ptrs)
+        extra_sets = []                           # (critic, dws, dbs): a pass that could not share, added afterwards
+
+        def new_set(c_idx):
+            dws = [torch.empty_like(w) for w in weights_of[c_idx]]
+            dbs = [torch.empty(shape, dtype=torch.float32, device=dev) for shape in critic_meta[c_idx][1]]
+            return dws, dbs, _ptr_array(dws), _ptr_array(dbs)
+
+        table, keep, dx_parts = [], [], [[] for _ in range(n_inputs)]
+        for p_idx, (x_idx, c_idx, widths_list, with_r1) in enumerate(pass_meta):
+            g_scores, g_norm2 = grads_in[p_idx]
+            want_params = need_params[c_idx] and (g_scores is not None or g_norm2 is not None)
+            want_x = need_x[x_idx] and g_scores is not None
+            if not want_params and not want_x:
+                continue
+            x2, saved, weights = x2s[x_idx], saveds[p_idx], weights_of[c_idx]
+            layers = len(weights) - 1
             b = x2.shape[0]
             gs = g_scores.contiguous() if g_scores is not None else None
-            gn = g_norm2.contiguous() if g_norm2 is not None else None
-            dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if need_x else None
-            dws = dbs = None
-            if need_params:
-                dws = [torch.empty_like(w) for w in weights]
-                dbs = [torch.empty(s, dtype=torch.float32, device=dev) for s in bias_shapes]
-            elif not need_x:
-                results.append((None, None, None, n_lin, x_shape))
-                continue
+            gn = g_norm2.contiguous() if (g_norm2 is not None and want_params) else None
+            dx = torch.empty(b, widths_list[0], dtype=torch.float32, device=dev) if want_x else None
+            dw_ptrs = db_ptrs = None
+            if want_params:
+                if param_grads[c_idx] is None:
+                    param_grads[c_idx] = new_set(c_idx)
+                    _, _, dw_ptrs, db_ptrs = param_grads[c_idx]
+                elif _critic_chainable(widths_list, layers, b, x2):
+                    _, _, dw_ptrs, db_ptrs = param_grads[c_idx]  # the library adds this pass's sums to the set
+                else:
+                    dws, dbs, dw_ptrs, db_ptrs = new_set(c_idx)
+                    extra_sets.append((c_idx, dws, dbs))
             widths = (ctypes.c_int32 * (layers + 1))(*widths_list)
             w_ptrs = _ptr_array(weights)
-            dw_ptrs = _ptr_array(dws) if dws is not None else None
-            db_ptrs = _ptr_array(dbs) if dbs is not None else None
-            table += [gs.data_ptr() if gs is not None else 0, gn.data_ptr() if (gn is not None and need_params) else 0,
+            table += [gs.data_ptr() if gs is not None else 0, gn.data_ptr() if gn is not None else 0,
                       x2.data_ptr(), x2.stride(0) if b > 0 else widths_list[0], b, layers, ctypes.addressof(widths),
                       ctypes.addressof(w_ptrs), saved.data_ptr(), ctypes.addressof(dw_ptrs) if dw_ptrs is not None else 0,
                       ctypes.addressof(db_ptrs) if db_ptrs is not None else 0, dx.data_ptr() if dx is not None else 0]
-            keep.append((widths, w_ptrs, dw_ptrs, db_ptrs, gs, gn))
-            results.append((dx, dws, dbs, n_lin, x_shape))
+            keep.append((widths, w_ptrs, gs, gn))
+            if dx is not None:
+                dx_parts[x_idx].append((dx, widths_list[0]))
+        # a critic whose first pass cannot take the chain route must not share at all: its later passes were given
+        # the same arrays above only if they are chainable, which the first pass then is as well (same widths, same
+        # batch); passes over different batch sizes fall under the library's own check
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
         if table:
             count = len(table) // 12
             arr = (ctypes.c_int64 * len(table))(*table)
             ws = _workspace(_lib.value("hivt_critics_bwd_workspace_bytes", arr, count), dev)
-            _lib.call("hivt_critics_bwd", arr, count, neg_slope, dropout_p, _p(ws), ws.numel(),
-                      torch._C._cuda_getCurrentRawStream(dev.index))
+            _lib.call("hivt_critics_bwd", arr, count, neg_slope, dropout_p, _p(ws), ws.numel(), stream)
         del keep
+        for c_idx, dws, dbs in extra_sets:
+            torch._foreach_add_(param_grads[c_idx][0] + param_grads[c_idx][1], dws + dbs)
         grads = [None, None]
-        for dx, dws, dbs, n_lin, x_shape in results:
-            grads.append(dx.view(x_shape) if dx is not None else None)
-            if dws is None:
+        for i in range(n_inputs):
+            parts = dx_parts[i]
+            if not parts:
+                grads.append(None)
+                continue
+            width = x2s[i].shape[1]
+            if len(parts) == 1 and parts[0][1] == width:
+                grads.append(parts[0][0].view(x_shapes[i]))
+                continue
+            total = None
+            for first in range(0, len(parts), 4 if len(parts) <= 4 else 3):
+                chunk = parts[first:first + (4 if len(parts) <= 4 else 3)]
+                if total is not None:
+                    chunk = [(total, width)] + chunk
+                out = torch.empty(x2s[i].shape[0], width, dtype=torch.float32, device=dev)
+                _lib.call("hivt_sum_padded_rows", _ptr_array([t for t, _ in chunk]),
+                          (ctypes.c_int32 * len(chunk))(*[w for _, w in chunk]), len(chunk), x2s[i].shape[0], width,
+                          _p(out), stream)
+                total = out
+            grads.append(total.view(x_shapes[i]))
+        for c_idx, (n_lin, _) in enumerate(critic_meta):
+            if param_grads[c_idx] is None:
                 grads += [None] * (2 * n_lin)
             else:
+                dws, dbs, _, _ = param_grads[c_idx]
                 for dw, db in zip(dws, dbs):
                     grads += [dw, db]
         return tuple(grads)
@@ -1512,17 +1642,26 @@ class _CriticsMulti(torch.autograd.Function):
 
 def critic_scores_multi(passes, neg_slope: float, dropout_p: float, training: bool):
     """``passes``: tuples ``(x, weights, biases, with_input_grad_norm)``, one per critic pass (the layout of
-    ``critic_scores``; all passes share the LeakyReLU slope and the dropout rate).  Returns per pass ``scores`` or
+    ``critic_scores``; all passes share the LeakyReLU slope and the dropout rate).  ``x`` may hold more columns per
+    flattened row than the critic's first layer reads (a longer trajectory than the critic's horizon): the pass
+    takes the leading ones.  Passes that name the same weight tensors are passes of ONE critic (their parameter
+    gradients come out summed), passes that name the same ``x`` share its gradient.  Returns per pass ``scores`` or
     ``(scores, grad_norm2)``; all passes run in one library call forward and one backward."""
     p = float(dropout_p) if training else 0.0
-    plan, tensors = [], []
+    xs, x_index, critics, critic_index, plan, tensors = [], {}, [], {}, [], []
     for x, weights, biases, with_r1 in passes:
         if len(weights) != len(biases) or not 2 <= len(weights) <= 9:
             raise ValueError("a critic has 1..8 hidden layers and an output layer")
-        plan.append((len(weights), bool(with_r1), _fresh_seed() if p > 0.0 else 0))
-        tensors.append(x)
-        tensors += [t for pair in zip(weights, biases) for t in pair]
-    outs = _CriticsMulti.apply((float(neg_slope), p), tuple(plan), *tensors)
+        if id(x) not in x_index:
+            x_index[id(x)] = len(xs)
+            xs.append(x)
+        key = tuple(id(t) for pair in zip(weights, biases) for t in pair)
+        if key not in critic_index:
+            critic_index[key] = len(critics)
+            critics.append(len(weights))
+            tensors += [t for pair in zip(weights, biases) for t in pair]
+        plan.append((x_index[id(x)], critic_index[key], bool(with_r1), _fresh_seed() if p > 0.0 else 0))
+    outs = _CriticsMulti.apply((float(neg_slope), p), (len(xs), tuple(critics), tuple(plan)), *xs, *tensors)
     result, at = [], 0
     for _, _, _, with_r1 in passes:
         if with_r1:
@@ -2109,3 +2248,500 @@ def step_guards(nan_check: Optional[torch.Tensor], finite_check: Optional[torch.
     _lib.call("hivt_step_guards", _p(a), a.numel() if a is not None else 0, _p(b), b.numel() if b is not None else 0,
               _p(ex), _p(flag), _stream(ref))
     return flag.view(torch.bool)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# Row bookkeeping of a batch in single launches (hivt_gan_amd/csrc/rows.hip)
+# --------------------------------------------------------------------------------------------
+def _u8(t: torch.Tensor) -> torch.Tensor:
+    t = t.contiguous()
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+def batch_prepare_supported(data, historical_steps: int) -> bool:
+    """Whether ``batch_prepare`` applies: a GPU batch with the reference's tensor types."""
+    x = data.get("x")
+    if x is None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or x.shape[2] != 2:
+        return False
+    pm = data.get("padding_mask")
+    if pm is None or pm.dtype not in (torch.bool, torch.uint8) or pm.shape[1] < historical_steps:
+        return False
+    for key in ("is_intersections", "turn_directions", "traffic_controls"):
+        t = data.get(key)
+        if t is None or t.dtype not in (torch.uint8, torch.bool):
+            return False
+    return data.get("rotate_angles") is not None and x.shape[1] >= historical_steps
+
+
+def batch_prepare(data, historical_steps: int) -> dict:
+    """Everything the step derives from the raw batch before the first layer, in one launch: ``rotate_mat``
+    [N, 2, 2], the targets rotated into the agents' frames (``y``, or None), ``x_rot`` [T * N, 2] (step-major rotated
+    displacements; ``x_steps``: the un-rotated ones in the same order), ``lane_code`` int32 [L], ``keep_w`` [N] (1 where an agent has a valid future step) and
+    ``keep_count`` (device scalar: their number, at least 1)."""
+    x = data["x"]
+    n = int(x.shape[0])
+    T = int(historical_steps)
+    dev = x.device
+    pm = _u8(data["padding_mask"])
+    hf = int(pm.shape[1]) - T
+    y = data.get("y")
+    if y is not None:
+        if y.dtype != torch.float32 or tuple(y.shape) != (n, hf, 2):
+            raise ValueError(f"y must be float32 [N, {hf}, 2], got {y.dtype} {tuple(y.shape)}")
+        y = y.contiguous()
+    ang = data["rotate_angles"].contiguous()
+    if ang.dtype != torch.float32 or ang.shape != (n,):
+        raise ValueError("rotate_angles must be float32 [N]")
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    lanes = [_u8(data[k]) for k in ("is_intersections", "turn_directions", "traffic_controls")]
+    num_lanes = int(lanes[0].shape[0])
+    rot = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
+    y_rot = torch.empty(n, hf, 2, dtype=torch.float32, device=dev) if y is not None else None
+    x_rot = torch.empty(T * n, 2, dtype=torch.float32, device=dev)
+    x_steps = torch.empty(T * n, 2, dtype=torch.float32, device=dev)
+    lane_code = torch.empty(num_lanes, dtype=torch.int32, device=dev)
+    keep_w = torch.empty(n, dtype=torch.float32, device=dev)
+    keep_count = torch.empty((), dtype=torch.float32, device=dev)
+    _lib.call("hivt_batch_prepare", _p(ang), _p(y), _p(x), x.stride(0), x.stride(1), _p(pm), pm.stride(0), _p(lanes[0]),
+              _p(lanes[1]), _p(lanes[2]), n, T, hf, num_lanes, _p(rot), _p(y_rot), _p(x_rot), _p(x_steps), _p(lane_code),
+              _p(keep_w), _p(keep_count), _stream(x))
+    return {"rotate_mat": rot, "y": y_rot, "x_rot": x_rot, "x_steps": x_steps, "lane_code": lane_code, "keep_w": keep_w,
+            "keep_count": keep_count}
+
+
+def row_subset_fixed(padding_mask: torch.Tensor, steps: int, capacity: int, rowptr: Optional[torch.Tensor],
+                     edge_counts=(), edge_caps=()) -> RowSubset:
+    """``row_subset`` of the (step, agent) nodes with ``~padding_mask[:, :steps]`` at a fixed capacity, in two
+    launches and without a read-back; ``overflow`` also covers the given device edge counters against their
+    capacities (the flag a fixed-capacity step discards its batch by)."""
+    _need_gpu(padding_mask)
+    pm = _u8(padding_mask)
+    n = int(pm.shape[0])
+    dev = pm.device
+    capacity = max(int(capacity), 1)
+    m = n * int(steps)
+    rows = torch.empty(capacity, dtype=torch.int32, device=dev)
+    new_id = torch.empty(m, dtype=torch.int32, device=dev)
+    live = torch.empty(capacity, dtype=torch.bool, device=dev)
+    count = torch.empty(2, dtype=torch.int32, device=dev)
+    overflow = torch.empty(1, dtype=torch.bool, device=dev)
+    packed = torch.empty(capacity + 1, dtype=torch.int32, device=dev) if rowptr is not None else None
+    if rowptr is not None and (rowptr.dtype != torch.int32 or rowptr.shape[0] != m + 1):
+        raise ValueError("rowptr must be int32 with steps * N + 1 entries")
+    cnt = list(edge_counts) + [None] * (3 - len(edge_counts))
+    cap = [int(c) for c in edge_caps] + [0] * (3 - len(edge_caps))
+    _lib.call("hivt_row_subset", _p(pm), pm.stride(0), n, int(steps), capacity, _p(rowptr), _p(cnt[0]), cap[0], _p(cnt[1]),
+              cap[1], _p(cnt[2]), cap[2], _p(rows), _p(new_id), _p(live), _p(count), _p(packed), _p(overflow), _stream(pm))
+    return RowSubset(rows, new_id, live, count[0], capacity, m, packed, overflow.view(()))
+
+
+def center_rows(x_rot: torch.Tensor, bos_mask: torch.Tensor, rows: torch.Tensor, n: int, steps: int
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per packed (step, agent) node: its rotated displacement [capacity, 2] and its begin-of-sequence code (the
+    step where ``bos_mask[agent, step]``, else -1)."""
+    bos = _u8(bos_mask)
+    cap = int(rows.shape[0])
+    xc = torch.empty(cap, 2, dtype=torch.float32, device=x_rot.device)
+    code = torch.empty(cap, dtype=torch.int32, device=x_rot.device)
+    _lib.call("hivt_center_rows", _p(x_rot), _p(bos), bos.stride(0), _p(rows), int(n), int(steps), cap, _p(xc), _p(code),
+              _stream(x_rot))
+    return xc, code
+
+
+class _RowsPutTokens(torch.autograd.Function):
+    """``where(code >= 0, token[code], x)`` for x [M, D], code int32 [M] (-1: keep the row), token [R <= 32, D]."""
+
+    @staticmethod
+    def forward(ctx, x, code, token):
+        _need_gpu(x, code, token)
+        x2 = _rows(x)
+        m, d = x2.shape
+        token_c = token.contiguous()
+        out = torch.empty(m, d, dtype=torch.float32, device=x.device)
+        _lib.call("hivt_rows_put_tokens", _p(x2), x2.stride(0), _p(code), _p(token_c), m, d, 0, _p(out), _stream(x))
+        ctx.save_for_backward(code)
+        ctx.codes = int(token.shape[0])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        dy = _rows(dy)
+        m, d = dy.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(m, d, dtype=torch.float32, device=dy.device)
+            _lib.call("hivt_rows_put_tokens", _p(dy), dy.stride(0), _p(code), None, m, d, 0, _p(dx), _stream(dy))
+        dtoken = _rowsum_by_code(dy, code, ctx.codes) if ctx.needs_input_grad[2] else None
+        return dx, None, dtoken
+
+
+def rows_put_tokens(x: torch.Tensor, code: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
+    """Rows whose ``code`` is non-negative replaced by ``token[code]`` (one launch; the token's gradient is a
+    per-code row sum in a fixed order)."""
+    if x.shape[-1] % 4 != 0 or token.shape[0] > 32:
+        raise _unsupported(f"token rows of width {x.shape[-1]} over {token.shape[0]} codes")
+    return _RowsPutTokens.apply(x, code, token)
+
+
+class _TemporalInput(torch.autograd.Function):
+    """Input of the temporal encoder, ``models/local_encoder.py:230-232``: for step s < T row (s, n) is the padding
+    token of step s where ``padding_mask[n, s]``, else the agent-agent stage's row (packed rows looked up through
+    ``new_id``), row (T, n) the class token; the positional row of the step is added to all of them."""
+
+    @staticmethod
+    def forward(ctx, x, new_id, rows, count, padding_mask, pad_token, cls_token, pos_embed):
+        _need_gpu(x, padding_mask, pad_token)
+        pm = _u8(padding_mask)
+        n = int(pm.shape[0])
+        steps, d = int(pad_token.shape[0]), int(pad_token.shape[1])
+        x2 = x.reshape(-1, d).contiguous()
+        pad_c, cls_c, pos_c = pad_token.contiguous(), cls_token.contiguous(), pos_embed.contiguous()
+        out = torch.empty(steps + 1, n, d, dtype=torch.float32, device=x.device)
+        pad_code = torch.empty((steps + 1) * n, dtype=torch.int32, device=x.device)
+        _lib.call("hivt_temporal_input_fwd", _p(x2), _p(new_id), _p(pm), pm.stride(0), _p(pad_c), _p(cls_c), _p(pos_c),
+                  steps, n, d, _p(out), _p(pad_code), _stream(x))
+        ctx.save_for_backward(rows, count, pad_code)
+        ctx.cfg = (steps, n, d, tuple(x.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        rows, count, pad_code = ctx.saved_tensors
+        steps, n, d, x_shape = ctx.cfg
+        dy2 = dy.contiguous().view((steps + 1) * n, d)
+        dev = dy2.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if rows is not None:
+                cap = int(rows.shape[0])
+                dx = torch.empty(cap, d, dtype=torch.float32, device=dev)
+                _lib.call("hivt_gather_live_rows", _p(dy2), _p(rows), _p(count), cap, d, _p(dx), _stream(dy2))
+            else:  # every (step, agent) row was an input row: the gradient is dy outside the padded rows
+                dx = torch.empty(steps * n, d, dtype=torch.float32, device=dev)
+                _lib.call("hivt_rows_put_tokens", _p(dy2), d, _p(pad_code), None, steps * n, d, 0, _p(dx), _stream(dy2))
+            dx = dx.view(x_shape)
+        dpad = _rowsum_by_code(dy2, pad_code, steps) if ctx.needs_input_grad[5] else None
+        dpos = dcls = None
+        if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+            dpos = _rowsum_by_code(dy2, _codes(steps + 1, n, dev), steps + 1)
+            dcls = dpos[steps] if ctx.needs_input_grad[6] else None
+        return dx, None, None, None, None, dpad, dcls, dpos
+
+
+def temporal_input(x: torch.Tensor, subset: Optional[RowSubset], padding_mask: torch.Tensor, pad_token: torch.Tensor,
+                   cls_token: torch.Tensor, pos_embed: torch.Tensor) -> torch.Tensor:
+    """[T + 1, N, D] input of the temporal encoder in one launch.  ``x``: the agent-agent stage's rows, packed
+    ([subset.capacity, D]) with ``subset`` or all of them ([T, N, D]) without; ``padding_mask`` [N, >= T]; pad_token
+    [T, D], cls_token [D], pos_embed [T + 1, D]."""
+    if subset is not None:
+        if subset.num_rows != padding_mask.shape[0] * pad_token.shape[0] or x.shape[0] != subset.capacity:
+            raise ValueError("temporal_input: the subset does not belong to this node set")
+        return _TemporalInput.apply(x, subset.new_id, subset.rows, subset.count.view(1), padding_mask, pad_token,
+                                    cls_token, pos_embed)
+    return _TemporalInput.apply(x, None, None, None, padding_mask, pad_token, cls_token, pos_embed)
+
+
+class _CategoryTable(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        _need_gpu(a, b, c)
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        d = int(a.shape[1])
+        out = torch.empty(a.shape[0] * b.shape[0] * c.shape[0], d, dtype=torch.float32, device=a.device)
+        _lib.call("hivt_category_table_fwd", _p(a), _p(b), _p(c), a.shape[0], b.shape[0], c.shape[0], d, _p(out),
+                  _stream(a))
+        ctx.sizes = (int(a.shape[0]), int(b.shape[0]), int(c.shape[0]), d)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        na, nb, nc, d = ctx.sizes
+        g = g.contiguous()
+        da = torch.empty(na, d, dtype=torch.float32, device=g.device)
+        db = torch.empty(nb, d, dtype=torch.float32, device=g.device)
+        dc = torch.empty(nc, d, dtype=torch.float32, device=g.device)
+        _lib.call("hivt_category_table_bwd", _p(g), na, nb, nc, d, _p(da), _p(db), _p(dc), _stream(g))
+        return da, db, dc
+
+
+def category_table(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """``[(a[i] + b[j]) + c[k]]`` for all (i, j, k), row ``(i * len(b) + j) * len(c) + k``: the summed categorical
+    embeddings of ``models/local_encoder.py:361-363`` as one small table (one launch, one for its gradient)."""
+    return _CategoryTable.apply(a, b, c)
+
+
+class _DecoderOutput(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, loc, raw, modes, agent_major, min_scale):
+        _need_gpu(loc, raw)
+        loc2, raw2 = _rows2(loc), _rows2(raw)
+        m, two_h = loc2.shape
+        h = two_h // 2
+        out = torch.empty(modes, m // modes, h, 4, dtype=torch.float32, device=loc.device)
+        f = modes if agent_major else 1
+        _lib.call("hivt_decoder_output_fwd", _p(loc2), loc2.stride(0), _p(raw2), raw2.stride(0), m, h, f, float(min_scale),
+                  _p(out), _stream(loc))
+        ctx.save_for_backward(raw2)
+        ctx.cfg = (m, h, f, float(min_scale), tuple(loc.shape), tuple(raw.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (raw2,) = ctx.saved_tensors
+        m, h, f, min_scale, loc_shape, raw_shape = ctx.cfg
+        g = g.contiguous()
+        d_loc = torch.empty(m, 2 * h, dtype=torch.float32, device=g.device)
+        d_raw = torch.empty(m, 2 * h, dtype=torch.float32, device=g.device)
+        _lib.call("hivt_decoder_output_bwd", _p(g), _p(raw2), raw2.stride(0), m, h, f, min_scale, _p(d_loc), _p(d_raw),
+                  _stream(g))
+        return d_loc.view(loc_shape), d_raw.view(raw_shape), None, None, None
+
+
+def decoder_output(loc: torch.Tensor, scale_raw: torch.Tensor, modes: int, agent_major: bool,
+                   min_scale: float = 0.05) -> torch.Tensor:
+    """``cat(loc, clamp(elu(scale_raw) + 1, min=min_scale))`` viewed [modes, N, H, 4] (``models/decoder.py:131-139``)
+    from the two heads' outputs [modes * N, 2 H]; ``agent_major``: their rows are ordered (agent, mode)."""
+    return _DecoderOutput.apply(loc, scale_raw, int(modes), bool(agent_major), float(min_scale))
+
+
+# --------------------------------------------------------------------------------------------
+# The adversarial objectives of all critic scales in single launches
+# --------------------------------------------------------------------------------------------
+class _HingeR1Multi(torch.autograd.Function):
+    """``out[0] = sum_k loss_k``, ``out[1 + 2k] = loss_k``, ``out[2 + 2k] = r1_k`` over K critic scales (inputs:
+    s_real_0, grad_norm2_0, s_fake_0, s_real_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, w, count, lambda_r1, *rows):
+        scales = len(rows) // 3
+        rows = [t.contiguous() for t in rows]
+        _need_gpu(w, count, *rows)
+        b = rows[0].shape[0]
+        for t in rows:
+            if t.shape != (b,) or t.dtype != torch.float32:
+                raise ValueError("hinge_r1_multi: every score / gradient-norm vector must be float32 [B]")
+        w = w.contiguous()
+        out = torch.empty(1 + 2 * scales, dtype=torch.float32, device=w.device)
+        _lib.call("hivt_hinge_r1_multi_fwd", _ptr_array(rows[0::3]), _ptr_array(rows[1::3]), _ptr_array(rows[2::3]), scales,
+                  _p(w), _p(count), b, float(lambda_r1), _p(out), _stream(w))
+        ctx.save_for_backward(w, count, *rows[0::3], *rows[2::3])
+        ctx.cfg = (scales, float(lambda_r1))
+        total, logs = out[0], out[1:]
+        ctx.mark_non_differentiable(logs)  # only the total is an objective
+        return total, logs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, _g_logs):
+        scales, lambda_r1 = ctx.cfg
+        w, count, *rest = ctx.saved_tensors
+        s_real, s_fake = rest[:scales], rest[scales:]
+        b = w.shape[0]
+        g_total = g_total.contiguous()
+        grads = torch.empty(3 * scales, b, dtype=torch.float32, device=w.device)
+        g_real = [grads[3 * k] for k in range(scales)]
+        g_norm2 = [grads[3 * k + 1] for k in range(scales)]
+        g_fake = [grads[3 * k + 2] for k in range(scales)]
+        _lib.call("hivt_hinge_r1_multi_bwd", _p(g_total), _ptr_array(list(s_real)), _ptr_array(list(s_fake)), scales, _p(w),
+                  _p(count), b, lambda_r1, _ptr_array(g_real), _ptr_array(g_norm2), _ptr_array(g_fake), _stream(w))
+        return (None, None, None, *[grads[i] for i in range(3 * scales)])
+
+
+def hinge_r1_multi(terms, w: torch.Tensor, count: torch.Tensor, lambda_r1: float
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``terms``: per critic scale ``(s_real, grad_norm2, s_fake)`` (at most four scales).  Returns ``(total,
+    logs)``: the critics' objective -- the sum over the scales, in order, of ``mean_w relu(1 - s_real) + mean_w
+    relu(1 + s_fake) + lambda_r1 * r1`` -- and per scale that term and its ``r1 = mean_w grad_norm2``
+    (``mean_w(v) = sum(w * v) / count``; ``logs[2k]``, ``logs[2k + 1]``, no gradient)."""
+    if not 1 <= len(terms) <= 4:
+        raise ValueError("hinge_r1_multi: one to four scales")
+    flat = [t for term in terms for t in term]
+    return _HingeR1Multi.apply(w, count, float(lambda_r1), *flat)
+
+
+class _GeneratorTotal(torch.autograd.Function):
+    """``out[0] = (losses[0] + losses[1]) + out[1]``, ``out[1] = lambda_adv * sum_k out[2 + k]``, ``out[2 + k] =
+    -mean_w scores_k``."""
+
+    @staticmethod
+    def forward(ctx, losses, w, count, lambda_adv, *scores):
+        scales = len(scores)
+        scores = [t.contiguous() for t in scores]
+        _need_gpu(losses, w, count, *scores)
+        losses, w = losses.contiguous(), w.contiguous()
+        b = w.shape[0]
+        out = torch.empty(2 + scales, dtype=torch.float32, device=w.device)
+        _lib.call("hivt_generator_total_fwd", _p(losses), _ptr_array(scores), scales, _p(w), _p(count), b,
+                  float(lambda_adv), _p(out), _stream(w))
+        ctx.save_for_backward(w, count)
+        ctx.cfg = (scales, float(lambda_adv))
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_total, _g_parts):
+        scales, lambda_adv = ctx.cfg
+        w, count = ctx.saved_tensors
+        b = w.shape[0]
+        g_total = g_total.contiguous()
+        g_losses = torch.empty(2, dtype=torch.float32, device=w.device)
+        g_s = torch.empty(scales, b, dtype=torch.float32, device=w.device)
+        _lib.call("hivt_generator_total_bwd", _p(g_total), scales, _p(w), _p(count), b, lambda_adv, _p(g_losses),
+                  _ptr_array([g_s[k] for k in range(scales)]), _stream(w))
+        return (g_losses, None, None, None, *[g_s[k] for k in range(scales)])
+
+
+def generator_total(losses: torch.Tensor, scores, w: torch.Tensor, count: torch.Tensor, lambda_adv: float
+                    ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The generator's objective and its parts in one launch: ``(total, parts)`` with ``total = (reg_loss + cls_loss) +
+    g_adv`` for ``losses = (reg_loss, cls_loss)``, ``parts[0] = g_adv = lambda_adv * sum_k g_k`` and ``parts[1 + k] =
+    g_k = -mean_w scores_k`` per critic scale (``models/hivt.py:317-324``; the parts carry no gradient)."""
+    if not 1 <= len(scores) <= 4:
+        raise ValueError("generator_total: one to four scales")
+    return _GeneratorTotal.apply(losses, w, count, float(lambda_adv), *scores)
+
+
+# --------------------------------------------------------------------------------------------
+# The decoder's two input layers over [global | local] rows without materialising the concatenation
+# --------------------------------------------------------------------------------------------
+_tile_indices = {}
+
+
+def _tile_index(modes: int, n: int, agent_major: bool, device):
+    """For rows that pair every one of ``modes`` global rows with the local row of their agent: ``idx`` int32
+    [modes * n] = the agent of every row, and the grouping of the rows by agent (``rowptr`` [n + 1], ``perm``) that
+    the sum over an agent's rows runs in (ascending mode)."""
+    key = (modes, n, bool(agent_major), str(device))
+    hit = _tile_indices.get(key)
+    if hit is None:
+        if len(_tile_indices) > 32:
+            _tile_indices.clear()
+        rows = torch.arange(modes * n, dtype=torch.int64)
+        idx = (rows // modes) if agent_major else (rows % n)
+        perm = rows if agent_major else (rows % modes) * n + rows // modes  # grouped position a * modes + f -> row
+        rowptr = torch.arange(n + 1, dtype=torch.int64) * modes
+        hit = _tile_indices[key] = tuple(t.to(torch.int32).to(device) for t in (idx, rowptr, perm))
+    return hit
+
+
+class _DecoderInputs(torch.autograd.Function):
+    """``(LN_ReLU(cat(g, l_tiled) W_a^T + b_a), LN_ReLU(cat(l_tiled, g) W_p^T + b_p))`` (``models/decoder.py:117-126``:
+    ``aggr_embed`` and the first layer of ``pi``) for g [modes * N, D] global rows and l [N, D] local rows, each
+    local row paired with the ``modes`` global rows of its agent.  A Linear over a concatenation is the sum of two
+    products, and the local one is the same for all modes of an agent: it runs once per agent ([N, D] x [D, D]) and
+    enters the global product's epilogue as an added row -- neither concatenation exists, and the big product
+    reduces over D instead of 2 D."""
+
+    @staticmethod
+    def forward(ctx, g, l, modes, agent_major, w_a, b_a, gamma_a, beta_a, w_p, b_p, gamma_p, beta_p, eps):
+        _need_gpu(g, l, w_a, w_p)
+        g2, l2 = _rows2(g), _rows2(l)
+        m, d = g2.shape
+        n = l2.shape[0]
+        if m != modes * n or w_a.shape != (d, 2 * d) or w_p.shape != (d, 2 * d) or l2.shape[1] != d:
+            raise ValueError("decoder inputs: expected g [modes * N, D], l [N, D] and two [D, 2 D] weights")
+        dev = g.device
+        st = _stream(g)
+        idx, _, _ = _tile_index(modes, n, agent_major, dev)
+        w_a_c, w_p_c = w_a.contiguous(), w_p.contiguous()
+        params = [t.contiguous() for t in (b_a, gamma_a, beta_a, b_p, gamma_p, beta_p)]
+        b_a_c, gamma_a_c, beta_a_c, b_p_c, gamma_p_c, beta_p_c = params
+        fb = 4 * d  # byte offset of a weight's second column half
+        outs = []
+        # (weight half that multiplies g, half that multiplies l): aggr_embed reads [g | l], pi reads [l | g]
+        for w, off_g, off_l, bias, gamma, beta in ((w_a_c, 0, fb, b_a_c, gamma_a_c, beta_a_c),
+                                                   (w_p_c, fb, 0, b_p_c, gamma_p_c, beta_p_c)):
+            t = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_fwd", _p(l2), l2.stride(0), _p(w, off_l), 2 * d, _p(bias), None, 0, None, 0, None, None,
+                      0.0, EPI_NONE, 1.0, 0.0, 0, None, None, 0, n, d, d, _p(t), d, None, 0, None, st)
+            y = torch.empty(m, d, dtype=torch.float32, device=dev)
+            z = torch.empty(m, d, dtype=torch.float32, device=dev)
+            stats = torch.empty(m, 2, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_fwd", _p(g2), g2.stride(0), _p(w, off_g), 2 * d, None, _p(t), d, _p(idx), n,
+                      _p(gamma), _p(beta), float(eps), EPI_LN_RELU, 1.0, 0.0, 0, None, None, 0, m, d, d, _p(y), d, _p(z), d,
+                      _p(stats), st)
+            outs += [y, z, stats]
+        ctx.save_for_backward(g2, l2, w_a_c, w_p_c, gamma_a_c, beta_a_c, gamma_p_c, beta_p_c, outs[1], outs[2], outs[4],
+                              outs[5])
+        ctx.cfg = (int(modes), bool(agent_major), tuple(g.shape), tuple(l.shape))
+        ctx.leaves = (_all_leaves(w_a, b_a), _all_leaves(w_p, b_p))
+        ctx.norm_leaves = (_all_leaves(gamma_a, beta_a), _all_leaves(gamma_p, beta_p))
+        ctx.set_materialize_grads(False)
+        return outs[0], outs[3]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy_a, dy_p):
+        g2, l2, w_a, w_p, gamma_a, beta_a, gamma_p, beta_p, z_a, stats_a, z_p, stats_p = ctx.saved_tensors
+        modes, agent_major, g_shape, l_shape = ctx.cfg
+        m, d = g2.shape
+        n = l2.shape[0]
+        dev = g2.device
+        st = _stream(g2)
+        _, rowptr, perm = _tile_index(modes, n, agent_major, dev)
+        fb = 4 * d
+        dg = dl = None
+        grads = {}
+        items, keep, checks = [], [], []
+        for tag, dy, w, off_g, off_l, gamma, beta, z, stats, leaves, norm_leaves in (
+                ("a", dy_a, w_a, 0, fb, gamma_a, beta_a, z_a, stats_a, ctx.leaves[0], ctx.norm_leaves[0]),
+                ("p", dy_p, w_p, fb, 0, gamma_p, beta_p, z_p, stats_p, ctx.leaves[1], ctx.norm_leaves[1])):
+            if dy is None:
+                grads[tag] = (None, None, None, None)
+                continue
+            dy2 = _rows2(dy)
+            dz = torch.empty(m, d, dtype=torch.float32, device=dev)
+            dgamma, dbeta = _ln_backward(dy2, z, d, stats, gamma, beta, 1, m, d, None, dz, st, norm_leaves)
+            # the local product's gradient rows: every agent's sum over its modes, in a fixed order
+            dt = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_segment_sum_rows", _p(dz), d, d, _p(rowptr), _p(perm), n, _p(dt), d, st)
+            if ctx.needs_input_grad[0]:
+                nxt = torch.empty(m, d, dtype=torch.float32, device=dev)
+                _lib.call("hivt_linear_bwd_data", _p(dz), d, _p(w, off_g), 2 * d, m, d, d, None, 0, 1.0, _p(dg),
+                          d if dg is not None else 0, _p(nxt), d, st)
+                dg = nxt
+            if ctx.needs_input_grad[1]:
+                nxt = torch.empty(n, d, dtype=torch.float32, device=dev)
+                _lib.call("hivt_linear_bwd_data", _p(dt), d, _p(w, off_l), 2 * d, n, d, d, None, 0, 1.0, _p(dl),
+                          d if dl is not None else 0, _p(nxt), d, st)
+                dl = nxt
+            # the two column halves of the [D, 2 D] weight gradient are two products; the bias gradient is the
+            # column sum of dz
+            dw = torch.empty(d, 2 * d, dtype=torch.float32, device=dev)
+            db = torch.empty(d, dtype=torch.float32, device=dev)
+            pair = [[dz.data_ptr(), d, g2.data_ptr(), g2.stride(0), m, d, d, dw.data_ptr() + off_g, db.data_ptr(), 16],
+                    [dt.data_ptr(), d, l2.data_ptr(), l2.stride(0), n, d, d, dw.data_ptr() + off_l, 0, 16]]
+            if _may_defer(leaves):
+                _schedule_flush()
+                _deferred.append((pair[0], dev, (dz, g2), ((dw.data_ptr(), db.data_ptr()), leaves)))
+                _deferred.append((pair[1], dev, (dt, l2), None))
+            else:
+                items += pair[0] + pair[1]
+                keep += [dz, dt]
+            grads[tag] = (dw, db, dgamma, dbeta)
+        if items:
+            _launch_wgrad_group(items, len(items) // 10, dev)
+        ga, gp = grads["a"], grads["p"]
+        return (dg.view(g_shape) if dg is not None else None, dl.view(l_shape) if dl is not None else None, None, None,
+                ga[0], ga[1], ga[2], ga[3], gp[0], gp[1], gp[2], gp[3], None)
+
+
+def decoder_inputs(g: torch.Tensor, l: torch.Tensor, modes: int, agent_major: bool, aggr_lin: torch.nn.Linear,
+                   aggr_norm: torch.nn.LayerNorm, pi_lin: torch.nn.Linear, pi_norm: torch.nn.LayerNorm
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(relu(aggr_norm(aggr_lin(cat(g, l_tiled)))), relu(pi_norm(pi_lin(cat(l_tiled, g)))))`` for global rows g
+    [modes * N, D] and local rows l [N, D]; ``agent_major``: row ``a * modes + f`` of g belongs to agent a (else row
+    ``f * N + a``).  One autograd node, four launches forward."""
+    return _DecoderInputs.apply(g, l, int(modes), bool(agent_major), aggr_lin.weight, aggr_lin.bias, aggr_norm.weight,
+                                aggr_norm.bias, pi_lin.weight, pi_lin.bias, pi_norm.weight, pi_norm.bias,
+                                float(aggr_norm.eps))

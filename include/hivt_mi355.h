@@ -11,7 +11,9 @@
  *   - all buffers are caller-owned; the library never allocates device memory.  Scratch comes from
  *     a caller-provided workspace sized by the matching *_workspace_bytes() query (256-B aligned);
  *   - every launch goes to the passed hipStream_t (as void*), is asynchronous, and performs no
- *     host synchronisation; the library keeps no mutable global state and is re-entrant;
+ *     host synchronisation.  Calls are re-entrant; the only process-wide state is the operand-precision
+ *     mask of hivt_set_matmul_bf16() (read once per call) and the static scratch of
+ *     hivt_csr_build_static() (one array per GPU: calls that overlap on one GPU race);
  *   - row indices are int32; edge lists handed over by the framework (int64 [2,E] COO,
  *     row 0 = source j, row 1 = target i) are converted by the edge-construction entry points;
  *   - "CSR order" = edges sorted by target, ties in original list order (stable), which is the
@@ -122,6 +124,99 @@ int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t 
 #define HIVT_CSR_STATIC_MAX_ROWS (1 << 20)
 int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,
                           int32_t* perm, hivt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row bookkeeping of a batch (index arithmetic, masks and token rows that the reference writes as
+ * dozens of small tensor operations per step)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Everything the step derives from the raw batch before the first layer runs, in one launch:
+ *   rotate_mat[n] = [[cos a, -sin a], [sin a, cos a]], y_rot = y @ rotate_mat (models/hivt.py:153-162;
+ *   y may be NULL), x_rot[t*N + n] = x[n, t] @ rotate_mat[n] for t < T (models/local_encoder.py:135-149,
+ *   step-major rows as the batched agent-agent stage numbers its nodes) and x_steps[t*N + n] = x[n, t] (the
+ *   un-rotated rows in the same order, which the edge gather looks its sources up in),
+ *   lane_code[l] = (is_intersections[l] * 3 + turn_directions[l]) * 2 + traffic_controls[l] (one row of the
+ *   12-row table that sums the three categorical embeddings, models/local_encoder.py:332-334,361-363),
+ *   keep_w[n] = 1 if agent n has a valid future step (padding_mask[n, T .. T+Hf) not all set), else 0, and
+ *   keep_count[0] = max(sum keep_w, 1) (the masked means of models/hivt.py:227-231 without boolean indexing).
+ * x float [N, *, 2] with element strides; padding_mask uint8 [N, pm_stride >= T + Hf]; lane attributes uint8 [L]. */
+int hivt_batch_prepare(const float* rotate_angles, const float* y, const float* x, int64_t x_stride_n,
+                       int64_t x_stride_t, const uint8_t* padding_mask, int64_t pm_stride,
+                       const uint8_t* is_intersections, const uint8_t* turn_directions,
+                       const uint8_t* traffic_controls, int32_t N, int32_t T, int32_t Hf, int32_t L,
+                       float* rotate_mat, float* y_rot, float* x_rot, float* x_steps, int32_t* lane_code,
+                       float* keep_w, float* keep_count, hivt_stream_t stream);
+
+/* The (step, agent) nodes t*N + n with padding_mask[n][t] == 0, packed in ascending order into `capacity` rows:
+ * the agent-agent stage's result at a padded node is overwritten by the padding token before anything reads it
+ * (models/local_encoder.py:230), so the stage runs on these rows only.
+ *   rows[capacity]        node id of every packed row; rows at or beyond the live count repeat the first live node
+ *   new_id[T*N]           packed position of a node, clamped into [0, capacity)
+ *   live[capacity]        1 for packed rows below the live count
+ *   count[2]              live count (unclamped), id of the first live node
+ *   packed_rowptr[capacity + 1]  rowptr (int32 [T*N + 1], a CSR over all nodes whose padded nodes own no
+ *                         edges) re-indexed to packed rows; both NULL to skip
+ *   overflow[0]           1 if the live count exceeds capacity or any *edge_countK exceeds edge_capK (K = 0..2,
+ *                         NULL counters are skipped): the flag a fixed-capacity step discards its batch by. */
+int hivt_row_subset(const uint8_t* padding_mask, int64_t pm_stride, int32_t N, int32_t T, int32_t capacity,
+                    const int32_t* rowptr, const int32_t* edge_count0, int64_t edge_cap0, const int32_t* edge_count1,
+                    int64_t edge_cap1, const int32_t* edge_count2, int64_t edge_cap2, int32_t* rows, int32_t* new_id,
+                    uint8_t* live, int32_t* count, int32_t* packed_rowptr, uint8_t* overflow, hivt_stream_t stream);
+
+/* Per packed row r (node m = rows[r], step t = m / N, agent n = m % N): xc[r] = x_rot[m] and
+ * code[r] = bos_mask[n][t] ? t : -1 -- the inputs of center_embed and of the begin-of-sequence substitution
+ * (models/local_encoder.py:149-150) for the packed nodes. */
+int hivt_center_rows(const float* x_rot, const uint8_t* bos_mask, int64_t bos_stride, const int32_t* rows, int32_t N,
+                     int32_t T, int32_t capacity, float* xc, int32_t* code, hivt_stream_t stream);
+
+/* out[m] = code[m] >= 0 ? token[code[m]] : x[m]  (torch.where(bos_mask, bos_token[t], center_embed),
+ * models/local_encoder.py:150).  With token == NULL it is the gradient's mask: out[m] = x[m] where
+ * (code[m] >= 0) == (keep_coded != 0), zero elsewhere.  Rows of D floats, D % 4 == 0. */
+int hivt_rows_put_tokens(const float* x, int64_t x_ld, const int32_t* code, const float* token, int64_t M, int32_t D,
+                         int32_t keep_coded, float* out, hivt_stream_t stream);
+
+/* Input of the temporal encoder (models/local_encoder.py:230-232): for s < T
+ *   out[s, n] = (padding_mask[n][s] ? padding_token[s] : x[new_id[s*N + n]]) + pos_embed[s]
+ * and out[T, n] = cls_token + pos_embed[T].  new_id == NULL: x holds all T*N rows.  pad_code[(T+1)*N] receives s
+ * for rows that took the padding token and -1 elsewhere (the row codes of the token's gradient). */
+int hivt_temporal_input_fwd(const float* x, const int32_t* new_id, const uint8_t* padding_mask, int64_t pm_stride,
+                            const float* padding_token, const float* cls_token, const float* pos_embed, int32_t T,
+                            int32_t N, int32_t D, float* out, int32_t* pad_code, hivt_stream_t stream);
+
+/* dx[r] = r < *count ? dy[rows[r]] : 0 for r < capacity: the gradient of the gather new_id above. */
+int hivt_gather_live_rows(const float* dy, const int32_t* rows, const int32_t* count, int32_t capacity, int32_t D,
+                          float* dx, hivt_stream_t stream);
+
+/* Decoder output (models/decoder.py:131-139): out[o, h] = (loc[m, 2h], loc[m, 2h+1], s(raw[m, 2h]), s(raw[m, 2h+1]))
+ * with s(v) = max(elu(v) + 1, min_scale), and the gradient with respect to loc and raw (clamp passes the
+ * gradient where elu(v) + 1 >= min_scale).  Output rows o are mode-major (f * N + n, the reference's
+ * [F, N, H, 4]); with F <= 1 the input rows are in the same order (m = o), with F > 1 they are agent-major
+ * (m = n * F + f, the order in which multihead_proj leaves the modes of an agent, models/global_interactor.py:63-65). */
+int hivt_decoder_output_fwd(const float* loc, int64_t loc_ld, const float* scale_raw, int64_t raw_ld, int64_t M,
+                            int32_t H, int32_t F, float min_scale, float* out, hivt_stream_t stream);
+int hivt_decoder_output_bwd(const float* d_out, const float* scale_raw, int64_t raw_ld, int64_t M, int32_t H, int32_t F,
+                            float min_scale, float* d_loc, float* d_scale_raw, hivt_stream_t stream);
+
+/* out[(i * nb + j) * nc + k] = (a[i] + b[j]) + c[k]: the table of summed categorical embeddings that
+ * models/local_encoder.py:361-363 adds per edge (is_intersection, turn_direction, traffic_control), and the
+ * gradient of the three small tables from the gradient of that table (rows added in ascending order). */
+int hivt_category_table_fwd(const float* a, const float* b, const float* c, int32_t na, int32_t nb, int32_t nc, int32_t D,
+                            float* out, hivt_stream_t stream);
+int hivt_category_table_bwd(const float* g, int32_t na, int32_t nb, int32_t nc, int32_t D, float* da, float* db, float* dc,
+                            hivt_stream_t stream);
+
+/* out[n, h, :] = y_hat[best_mode[n], n, h, 0:2] for y_hat [F, N, H, C] (models/hivt.py:221-224), and its
+ * gradient ADDED in place to d_y_hat (which already holds the gradient of the other uses of y_hat). */
+int hivt_select_mode_fwd(const float* y_hat, const int64_t* best_mode, int32_t F, int32_t N, int32_t H, int32_t C,
+                         float* out, hivt_stream_t stream);
+int hivt_select_mode_bwd(const float* g, const int64_t* best_mode, int32_t F, int32_t N, int32_t H, int32_t C,
+                         float* d_y_hat, hivt_stream_t stream);
+
+/* out[b][c] = sum over parts p (in order) with c < widths[p] of parts[p][b * widths[p] + c]: the input gradients
+ * of critics that read the first widths[p] columns of the same rows (the horizon wrappers under models/critics slice
+ * their horizon out of one trajectory tensor).  parts: HOST array of 1..4 device pointers. */
+int hivt_sum_padded_rows(const float* const* parts, const int32_t* widths, int32_t count, int64_t B, int32_t W,
+                         float* out, hivt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Kernel (a): edge gather + rotation into the target's frame
@@ -311,7 +406,11 @@ int hivt_linear_wgrad(const float* dy, int64_t dy_ld, const float* x, int64_t x_
  * where a launch per product and per sum is all latency).  `items` holds `count` rows of ten int64:
  *   dy, dy_ld, x, x_ld, M, N, K, dw, dbias (0: none), flags
  * flags bit 0: the sums are added to what dw / dbias hold; bit 1: the term joins the item before it (same dw,
- * N, K; its sum is added to that item's; no bias term).  Results are those of hivt_linear_wgrad on the same
+ * N, K; its sum is added to that item's, terms in table order; up to three terms may join one item); bit 3,
+ * on a joining term: the column sums of its dy are added to the item's dbias as well (without it a joining
+ * term has no bias term); bit 4: dw points into a [N, 2K] matrix whose left or right half the item fills (rows 2K
+ * floats apart: the two halves of a Linear over concatenated inputs, models/decoder.py:119-126, are two items).
+ * Results are those of hivt_linear_wgrad on the same
  * item (torch.nn.Linear's weight.grad / bias.grad, as `loss.backward()` fills them in
  * models/hivt.py:283,312,325): bit-identical for terms that call cuts into fewer than 64 row chunks, equal to
  * rounding for longer ones (summed in chunks of about 2048 rows).  Sixteen terms per launch. */
@@ -537,6 +636,9 @@ int hivt_critic_bwd(const float* g_scores, const float* g_norm2, const float* x,
  *                      meaning of every field is that of the hivt_critic_fwd argument of the same name.
  *   hivt_critics_bwd   rows of 12 int64 -- g_scores, g_norm2, x, x_ld, B, layers, widths, w, saved, dw (host
  *                      float** or 0), dbias (host float** or 0), dx; as hivt_critic_bwd.
+ * Backward passes that are handed the SAME dw / dbias arrays (the passes of one critic over real and generated
+ * rows, whose weight gradients the optimizer wants summed) leave the sum of their gradients there; such passes
+ * must be built for the layer chain (see the last sentence).
  * Results are those of one hivt_critic_fwd / hivt_critic_bwd call per pass (scores: an fp32 dot product in
  * place of the matrix-core product, so equal to rounding).  Passes with more than four hidden layers, widths
  * that are not multiples of 4 or operands that are not 16-byte aligned take that single-pass route. */
@@ -559,6 +661,26 @@ int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_f
                       const float* count, int64_t B, float lambda_r1, float* g_real, float* g_norm2, float* g_fake,
                       hivt_stream_t stream);
 
+/* The critic loss of ALL scales in one launch (models/hivt.py:305-310: the per-scale terms above, summed in scale
+ * order): out[0] = sum_k out[1 + 2k], out[1 + 2k] = loss of scale k, out[2 + 2k] = its R1 penalty; s_real /
+ * grad_norm2 / s_fake are HOST arrays of `scales` (1..4) device pointers to B rows each.  The gradient of out[0]
+ * goes to g_real[k], g_norm2[k], g_fake[k] (HOST arrays of device pointers). */
+int hivt_hinge_r1_multi_fwd(const float* const* s_real, const float* const* grad_norm2, const float* const* s_fake,
+                            int32_t scales, const float* w, const float* count, int64_t B, float lambda_r1, float* out,
+                            hivt_stream_t stream);
+int hivt_hinge_r1_multi_bwd(const float* g_loss, const float* const* s_real, const float* const* s_fake, int32_t scales,
+                            const float* w, const float* count, int64_t B, float lambda_r1, float* const* g_real,
+                            float* const* g_norm2, float* const* g_fake, hivt_stream_t stream);
+
+/* The generator's objective in one launch (models/hivt.py:317-324, losses/adv_losses.py:91-98):
+ *   out[2 + k] = -sum_i w_i s_fake[k][i] / count,  out[1] = lambda_adv * sum_k out[2 + k] (scale order),
+ *   out[0] = (losses[0] + losses[1]) + out[1]   with losses = (regression, classification) loss.
+ * Gradient of out[0]: g_losses[0] = g_losses[1] = g_out, g_s[k][i] = -lambda_adv * g_out * w_i / count. */
+int hivt_generator_total_fwd(const float* losses, const float* const* s_fake, int32_t scales, const float* w,
+                             const float* count, int64_t B, float lambda_adv, float* out, hivt_stream_t stream);
+int hivt_generator_total_bwd(const float* g_out, int32_t scales, const float* w, const float* count, int64_t B,
+                             float lambda_adv, float* g_losses, float* const* g_s, hivt_stream_t stream);
+
 /* Guards of the training step in one pass (models/hivt.py:264,272,294): flag[0] = 1 if nan_check holds a
  * NaN, finite_check holds a NaN or an infinity, or *extra != 0 (extra: optional device byte, e.g. an
  * overflow flag); else 0.  flag is a device int32 written in full by every call (its first byte read as a
@@ -578,6 +700,15 @@ int hivt_adamw_step(const uint64_t* params, const uint64_t* grads, const uint64_
                     const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, const float* step,
                     const float* found_inf, float lr, float beta1, float beta2, float eps, float weight_decay,
                     hivt_stream_t stream);
+
+/* The same update for a caller that keeps `step` = number of updates done SO FAR: the update uses *step + 1 and the
+ * call then advances *step by one (one extra one-thread launch), unless found_inf == 1.  lr_ptr (optional device
+ * scalar) replaces lr, so that a learning-rate schedule needs no new launch arguments (a recorded graph keeps
+ * replaying while the schedule writes the scalar). */
+int hivt_adamw_update(const uint64_t* params, const uint64_t* grads, const uint64_t* exp_avgs,
+                      const uint64_t* exp_avg_sqs, const int64_t* numels, int32_t count, float* step,
+                      const float* found_inf, const float* lr_ptr, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, hivt_stream_t stream);
 
 /* Generator's adversarial term of one scale (losses/adv_losses.py:91-98): out = scale * sum_i w_i s_i / count
  * (scale = -1 for -mean D(fake)), and its gradient g_s_i = scale * g_out * w_i / count. */
