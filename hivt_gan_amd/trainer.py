@@ -55,7 +55,13 @@ class FlatGradBucket:
     every chunk is packed and handed to an asynchronous all-reduce from a post-accumulate hook as soon
     as its last gradient has arrived, so the collective runs beside the rest of the backward pass;
     ``finish`` packs what is left, waits, and hands the reduced values back to the parameters as views
-    of the buffer.  Without ``overlap`` everything happens in ``finish``: one pack, one all-reduce."""
+    of the buffer.  Without ``overlap`` everything happens in ``finish``: one pack, one all-reduce.
+
+    A rank that discarded its batch contributes ZEROS and the sum is still divided by the world size -- the
+    reference's behaviour: its skipped rank returns a zero-valued dummy loss precisely so that it enters the same
+    collectives (``models/hivt.py:262-265,301-310``), and DDP then averages over all ranks.  With k of W ranks
+    contributing the applied gradient is k / W of the contributors' mean; the trailing element of the buffer
+    carries that share k / W (``tests/test_dp_gloo.py`` pins both)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], chunks: Optional[List[List[torch.nn.Parameter]]] = None,
                  overlap: bool = False, group=None) -> None:
@@ -161,7 +167,9 @@ class FlatGradBucket:
         return self.flat[a:b + 1] if i == len(self.chunks) - 1 else self.flat[a:b]
 
     def _reduce(self, i: int, async_op: bool) -> None:
-        piece = self._span(i)
+        self._reduce_piece(self._span(i), async_op)
+
+    def _reduce_piece(self, piece: torch.Tensor, async_op: bool) -> None:
         if _is_rccl(self.group):  # RCCL averages inside the collective
             work = dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         elif piece.is_cuda:  # CPU backend with device tensors: staged through host memory
@@ -202,7 +210,15 @@ class FlatGradBucket:
         scalar; 0 means that every rank discarded its batch)."""
         if not self._armed:
             self.begin(bad)
-        self._launch_ready(force=True)
+        if not self.overlap:
+            # nothing goes out during the backward pass: the whole buffer, contribution flag included, in ONE
+            # collective -- the payload is latency-bound, so chunks would only add latencies.  (With overlap a
+            # rank without a backward pass must still issue the same chunked collectives as the others.)
+            self.pack(bad)
+            self._reduce_piece(self.flat, async_op=False)
+            self._next = -1
+        else:
+            self._launch_ready(force=True)
         for work in self._work:
             if isinstance(work, tuple):  # CPU backend: the sum still has to become a mean
                 work[0].wait()
@@ -218,11 +234,11 @@ class FlatGradBucket:
         return self.finish(bad)
 
     def reduce_packed(self) -> None:
-        """The collectives alone, on a buffer that ``pack`` has filled: every chunk in the canonical order,
-        blocking.  A recorded step calls this between two of its graph segments (the packing before it and
-        the update after it are recorded, the collectives are not)."""
-        for i in range(len(self.chunks) - 1, -1, -1):
-            self._reduce(i, async_op=False)
+        """The collective alone, on a buffer that ``pack`` has filled: ONE blocking all-reduce of the whole buffer
+        (all chunks and the contribution flag).  A recorded step calls this between two of its graph segments
+        (the packing before it and the update after it are recorded, the collective is not); nothing overlaps
+        there, so cutting the buffer into chunks would only add collective latencies."""
+        self._reduce_piece(self.flat, async_op=False)
 
 
 class _DataParallelSync:

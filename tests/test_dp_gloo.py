@@ -84,8 +84,23 @@ def worker(rank, world, port, poison_rank, out_dir, critic_steps=1, overlap=Fals
         batch = hv.make_batch(2, first_index=10 * rank)
         if rank == poison_rank:
             batch["y"][0, 0, 0] = float("nan")
-        logs = trainer.step(batch)
+        collectives = []
+        plain_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(tensor, *a, **k):
+            collectives.append(tensor.numel())
+            return plain_all_reduce(tensor, *a, **k)
+        dist.all_reduce = counting_all_reduce
+        try:
+            logs = trainer.step(batch)
+        finally:
+            dist.all_reduce = plain_all_reduce
         assert calls == ["critic"] * critic_steps + ["generator"], calls
+        if not overlap:
+            # one collective per optimizer group and backward pass (the whole flat buffer with its contribution
+            # flag), plus the one for the packed logs
+            sizes = [trainer.buckets["critic"].total + 1] * critic_steps + [trainer.buckets["generator"].total + 1]
+            assert collectives[:-1] == sizes and len(collectives) == len(sizes) + 1, (collectives, sizes)
         # the logs are averaged over the ranks that produced them, in one collective
         if poison_rank < 0:
             both = [None, None]
@@ -153,6 +168,38 @@ def test_two_rank_step_matches_manual_average(tmp_path, poison_rank, overlap):
         # one), so agreement is judged against the scale of the gradient vector
         err = float((dp[group] - ref[group]).abs().max())
         assert err <= 1e-6 * float(ref[group].abs().max()), f"{group} gradients differ by {err:.3e}"
+
+
+def discarding_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hivt_gan_amd.trainer import FlatGradBucket
+        params = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+        bucket = FlatGradBucket(params, overlap=False)
+        for step in range(2):  # the second pass starts from gradients that are views of the buffer
+            for i, p in enumerate(params):
+                g = torch.full_like(p, float(i + 1 + step))
+                if rank == 1:
+                    g[..., 0] = float("nan")  # what a discarded batch may leave behind
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.copy_(g)
+            share = bucket.finish(torch.tensor(rank == 1))
+            # the discarding rank enters the sum as zeros (selected, so its NaNs stay out) and the sum is still
+            # divided by the world size, as a zero-loss rank under the reference's DDP is
+            assert float(share) == 0.5
+            for i, p in enumerate(params):
+                assert torch.equal(p.grad, torch.full_like(p, (i + 1 + step) / 2)), (rank, step, p.grad)
+        share = bucket.finish(torch.tensor(True))
+        assert float(share) == 0.0 and all(float(p.grad.abs().max()) == 0.0 for p in params)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_discarding_rank_counts_as_a_zero_gradient_contributor():
+    mp.spawn(discarding_worker, args=(2, free_port()), nprocs=2, join=True)
 
 
 def test_two_critic_steps_with_a_poisoned_rank_stay_in_lock_step(tmp_path):
