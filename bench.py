@@ -14,18 +14,24 @@ with fp32 accumulation (everything else fp32; in memory only gradients that noth
 read are bfloat16); ``--matmul fp32`` runs the step in fp32 throughout.  The other setting is timed after
 the headline measurement and reported as ``matmul_variant``.
 
-The step is recorded once as a HIP graph on fixed shapes and replayed: the batches of the pool are padded
-to the pool's largest node / edge counts times ``--capacity-slack`` (``config.capacities``); a batch that
-did not fit would be discarded and counted in ``config.discarded_steps``.  A run makes one recording per
-distinct padded shape of the pool (data parallel: one per batch, so that all ranks make equally many) and
-replays, for each batch, the one of its own shape (``--no-buckets``: one recording at the largest shape).
+The step is recorded as a HIP graph on fixed shapes and replayed.  A rank cycles through a pool of ``--pool``
+distinct batches; the pool is spread over at most ``--max-recordings`` recorded shapes
+(``BatchSpec.shape_buckets``), each with ``--capacity-slack`` head room over its largest batch -- the head room
+``GanTrainer.calibrate`` gives by default, for batches it has not seen -- and every batch replays the recording
+of its bucket (padded rows are computed like real ones).  A batch that did not fit would be discarded and counted
+in ``config.discarded_steps``.  ``config.tuned_to_pool_variant`` is the same step on four batches at capacities
+fitted to exactly those batches (no head room).  Data parallel: batch i of every rank is padded to the largest
+capacities batch i has on any rank, so all ranks cut the same buckets and make the same recordings.
+``--no-buckets``: one recording at the pool's largest shape.
 
 The ``roofline`` object describes the edge-attention launch kind that takes the most time per step:
 algorithmic bytes of one launch divided by its average duration (the kernel's own start / stop time
 stamps).  Every launch kind is listed under ``edge_attention_kernels`` with, beside its fraction of
 8 TB/s, the time a plain device copy of the same byte count takes on this GPU in this run
 (``copy_same_bytes_us``; ``rate_vs_copy`` > 1 means the attention launch moves its bytes faster than
-that copy).  ``cpu_baseline`` times the CPU oracle's restatement of the same step on a bounded sample
+that copy).  ``dense_roofline`` prices the longest dense product of the step alone (the lane-actor edge rows
+through a 128 x 128 layer, forward and weight gradient): flop rate against the dense matrix-core peak of the
+operand type and byte rate against HBM.  ``cpu_baseline`` times the CPU oracle's restatement of the same step on a bounded sample
 of the same workload (rank 0, single-GPU runs only).
 """
 import argparse
@@ -140,7 +146,46 @@ class _Phases:
         self._undo = []
 
 
-def cpu_baseline(embed_dim: int, scenes: int, steps: int):
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.0}  # dense matrix-core peaks (no sparsity)
+
+
+def dense_roofline(dev, rows: int, width: int, matmul: str, launches: int = 20):
+    """The step's longest dense product priced alone on ``rows`` x ``width`` fp32 activations: the forward launch
+    ``y = x W^T + b`` and the weight-gradient call ``dW = dy^T x, db = column sums`` (one grouped call of one term),
+    each timed over ``launches`` back-to-back launches between two events on the stream they run on.  Flops are
+    the product's own 2 * rows * width^2 (the bf16 forward runs three matrix instructions per product on split
+    operands; that is not counted); bytes are the fp32 operands read and written once."""
+    x = torch.randn(rows, width, device=dev)
+    w = torch.randn(width, width, device=dev) * width ** -0.5
+    b = torch.zeros(width, device=dev)
+    dw, db = torch.empty_like(w), torch.empty_like(b)
+    flops = 2.0 * rows * width * width
+    nbytes = {"forward": 4.0 * (2 * rows * width + width * width + width),
+              "weight_gradient": 4.0 * (2 * rows * width + width * width + width)}
+    out = {"rows": rows, "k": width, "n": width, "operands": matmul, "peak_tflops": MFMA_PEAK_TFLOPS[matmul],
+           "peak_gbs": HBM_PEAK_GBS, "launches": launches}
+    with torch.no_grad():
+        y = ops.fused_linear(x, w, b)
+        calls = {"forward": lambda: ops.fused_linear(x, w, b),
+                 "weight_gradient": lambda: ops.linear_wgrad_group([(y, x, dw, db, False, False)])}
+        for name, call in calls.items():
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                call()
+            e1.record()
+            e1.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / launches
+            out[name] = {"us": sec * 1e6, "tflops": flops / sec / 1e12, "gbs": nbytes[name] / sec / 1e9,
+                         "frac_of_mfma_peak": flops / sec / 1e12 / MFMA_PEAK_TFLOPS[matmul],
+                         "frac_of_hbm_peak": nbytes[name] / sec / 1e9 / HBM_PEAK_GBS}
+    out["bound"] = "hbm"  # 64 flop per byte of fp32 operand at width 128: below either ridge point
+    return out
+
+
+def cpu_baseline(embed_dim: int, scenes: int, steps: int, warmup: int = 3):
     """The CPU oracle's G + D + R1 step (forward, both backwards, both AdamW updates) on a bounded
     sample of the same workload; returns scenes/sec on the host cores torch is allowed to use and the
     time per phase (edge construction, the three edge-attention stages, temporal encoder, decoder, losses,
@@ -182,11 +227,11 @@ def cpu_baseline(embed_dim: int, scenes: int, steps: int):
     ocfg["critic_update"] = critic_update
     times = []
     try:
-        for i in range(steps + 1):
+        for i in range(steps + warmup):
             batch = hv.make_batch(scenes, first_index=50_000 + i * scenes)
             data = {k: batch[k] for k in batch.keys()}
-            if i == 1:
-                phases.seconds.clear()  # the first step is warm-up
+            if i == warmup:
+                phases.seconds.clear()  # phases of the timed steps only
             t0 = time.perf_counter()
             res = O.gan_step_grads(gen_sd, cr_sd, data, ocfg, training=True)
             for p, k in zip(gen_params, [k for k, v in gen_sd.items() if v.requires_grad]):
@@ -195,11 +240,11 @@ def cpu_baseline(embed_dim: int, scenes: int, steps: int):
             times.append(time.perf_counter() - t0)
     finally:
         phases.restore()
-    med = statistics.median(times[1:])
+    med = statistics.median(times[warmup:])
     per_phase = {k: round(v / steps * 1e3, 1) for k, v in sorted(phases.seconds.items(), key=lambda kv: -kv[1])}
-    per_phase["other"] = round(max(sum(times[1:]) / steps * 1e3 - sum(per_phase.values()), 0.0), 1)
+    per_phase["other"] = round(max(sum(times[warmup:]) / steps * 1e3 - sum(per_phase.values()), 0.0), 1)
     return {"value": scenes / med, "unit": "scenes/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (+1 warm-up) of the CPU oracle's G+D+R1 step incl. AdamW on {scenes} "
+            "sample": f"{steps} timed steps (+{warmup} warm-up) of the CPU oracle's G+D+R1 step incl. AdamW on {scenes} "
                       f"synthetic scenes per step, HiVT-{embed_dim} fp32, median {med * 1e3:.0f} ms/step",
             "phase_ms_per_step": per_phase}
 
@@ -211,7 +256,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--embed-dim", type=int, default=128)
     ap.add_argument("--scenes", type=int, default=128, help="scenes per GPU per step")
-    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled per rank")
+    ap.add_argument("--pool", type=int, default=32, help="distinct synthetic batches cycled per rank")
+    ap.add_argument("--max-recordings", type=int, default=4,
+                    help="recorded shapes the pool's batches are spread over (each batch replays the smallest that holds it)")
+    ap.add_argument("--no-pool-fitted", action="store_true",
+                    help="skip the extra timing of four batches at capacities fitted to exactly those batches "
+                         "(reported as config.tuned_to_pool_variant, never as value)")
     ap.add_argument("--dense", action="store_true",
                     help="dense-scene stress shape instead of the headline workload: 200 agents and 1000 lane "
                          "segments per scene, 150 m radius, every step valid (use with --scenes 2..8)")
@@ -219,10 +269,10 @@ def main():
     ap.add_argument("--no-buckets", dest="buckets", action="store_false",
                     help="one recording at the pool's largest shape for every batch (default: one recording per distinct "
                          "padded shape of the pool)")
-    ap.add_argument("--capacity-slack", type=float, default=1.0,
-                    help="head room of the recorded step's fixed edge / node capacities over the largest batch of the "
-                         "pool (1.0: the pool is all the data this run sees; the library's default for a data stream "
-                         "is 1.1 for edges, 1.05 for nodes -- padded rows are computed like real ones)")
+    ap.add_argument("--capacity-slack", type=float, default=1.1,
+                    help="head room of the recorded step's fixed edge capacities over the largest batch of a shape bucket "
+                         "(nodes: at most 1.05); the default is GanTrainer.calibrate's own, what a run over a data stream "
+                         "uses -- padded rows are computed like real ones, so head room costs its share of the step")
     ap.add_argument("--matmul", choices=("fp32", "bf16"), default="bf16",
                     help="operand precision of the dense products: bf16 operands with fp32 accumulation (the named "
                          "workload's precision, results within 2e-2) or fp32 throughout (within 1e-5)")
@@ -235,7 +285,8 @@ def main():
     ap.add_argument("--host-guards", action="store_true",
                     help="evaluate the NaN / finite guards and edge counts on the host (three read-backs per step)")
     ap.add_argument("--cpu-scenes", type=int, default=128, help="scenes per step of the CPU baseline (the GPU step's batch)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed steps of the CPU baseline (median reported)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed steps of the CPU baseline before them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -311,36 +362,45 @@ def main():
                 graphed = None
 
     # Shape buckets: every padded row of a fixed-shape recording is computed like a real one, so a batch replays the
-    # recording of the smallest shape that holds it -- here one recording per distinct shape of the pool (node counts
-    # rounded up to 64, edge lists to 256).  All recordings share the model, the optimizers and their state.  If
-    # any of them cannot be made, the one recording at the pool's largest shape above serves every batch.
+    # recording of the smallest shape that holds it.  The pool's batches are spread over at most --max-recordings
+    # shapes (BatchSpec.shape_buckets: the cuts that leave the fewest padded rows), each with --capacity-slack head
+    # room over its largest batch.  All recordings share the model, the optimizers and their state.  If any of them
+    # cannot be made, the one recording at the pool's largest shape above serves every batch.
+    def record_buckets(batches, slack: float, max_recordings: int, first_seed: int):
+        """(recordings, bucket of every batch, every batch padded to its bucket's shape)."""
+        from hivt_gan_amd.graph import GraphedStep, pack_inputs
+        own = [hv.GanTrainer.calibrate(model, [b], slack=slack, node_slack=min(slack, 1.05)) for b in batches]
+        if world > 1:
+            # batch i of every rank at the same capacities (the largest of any rank): every rank then cuts the same
+            # buckets and makes the same number of recordings, whose warm-up steps hold collectives
+            caps = torch.tensor([sp.key() for sp in own], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(caps, op=dist.ReduceOp.MAX)
+            own = [hv.BatchSpec(c[0], c[1], c[2], c[3], edge_capacity=tuple(c[4:])) for c in caps.tolist()]
+        shapes, which = hv.BatchSpec.shape_buckets(own, max_recordings)
+        examples = [batches[which.index(j)] for j in range(len(shapes))]
+        graphs = [GraphedStep(trainer, sp, pack_inputs(hv.pad_batch(ex, sp)), seed_offset=first_seed + j,
+                              critic_streams=bool(tuned.get("critic_streams", False)))
+                  for j, (sp, ex) in enumerate(zip(shapes, examples))]
+        return graphs, which, [pack_inputs(hv.pad_batch(b, shapes[j])) for b, j in zip(batches, which)]
+
+    def all_ranks(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
     bucket_of, bucket_graphs, bucket_padded = None, [], []
     if graphed is not None and args.buckets:
-        # (under data parallelism every recording's warm-up steps hold collectives, so every rank makes the same
-        # number of recordings: one per batch of its pool, equal shapes or not)
         try:
-            from hivt_gan_amd.graph import GraphedStep, pack_inputs
-            shapes, bucket_of = {}, []
-            for b, _ in pool:
-                sp = hv.GanTrainer.calibrate(model, [b], slack=args.capacity_slack,
-                                             node_slack=min(args.capacity_slack, 1.05))
-                key = (sp.num_nodes, sp.num_lanes, sp.num_edges, sp.num_lane_actor, tuple(sp.edge_capacity))
-                if key not in shapes or world > 1:
-                    shapes[key] = len(bucket_graphs)
-                    example = pack_inputs(hv.pad_batch(b, sp))
-                    bucket_graphs.append(GraphedStep(trainer, sp, example, seed_offset=1 + len(bucket_graphs),
-                                                     critic_streams=bool(tuned.get("critic_streams", False))))
-                bucket_of.append(shapes[key])
-                bucket_padded.append(pack_inputs(hv.pad_batch(b, bucket_graphs[shapes[key]].spec)))
+            bucket_graphs, bucket_of, bucket_padded = record_buckets([b for b, _ in pool], args.capacity_slack,
+                                                                     args.max_recordings, 1)
         except Exception as exc:  # noqa: BLE001 -- the single recording stays in use
             if rank == 0:
                 print(f"warning: shape buckets not recorded ({type(exc).__name__}: {exc})", file=sys.stderr)
             bucket_of, bucket_graphs, bucket_padded = None, [], []
-        if world > 1:  # all ranks replay their own recordings or none does
-            ok = torch.tensor([1 if bucket_of is not None else 0], device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                bucket_of, bucket_graphs, bucket_padded = None, [], []
+        if not all_ranks(bucket_of is not None):  # all ranks replay their own recordings or none does
+            bucket_of, bucket_graphs, bucket_padded = None, [], []
 
     def run_step(i: int):
         if bucket_of is not None:
@@ -384,6 +444,28 @@ def main():
             eager_step(args.warmup + i)
         torch.cuda.synchronize()
         ops.SEG_ATTN_TIMING = None
+
+    # What the head room and the few shapes cost: the first four batches of the pool at capacities fitted to exactly
+    # those batches (no head room, one recording per distinct shape), timed the same way (reported beside the
+    # headline, never as ``value``)
+    fitted = None
+    if bucket_of is not None and not args.no_pool_fitted:
+        headline = (bucket_graphs, bucket_of, bucket_padded)
+        try:
+            few = [b for b, _ in pool[:4]]
+            bucket_graphs, bucket_of, bucket_padded = record_buckets(few, 1.0, len(few), 101)
+            for i in range(3):
+                run_step(i)
+            fitted = {"ms_per_step": timed(0, args.steps) / args.steps * 1e3, "pool": len(few), "capacity_slack": 1.0,
+                      "recordings": len(bucket_graphs), "nodes": [g.spec.num_nodes for g in bucket_graphs]}
+            fitted["value"] = world * args.scenes / fitted["ms_per_step"] * 1e3
+        except Exception as exc:  # noqa: BLE001 -- an extra, never the headline
+            if rank == 0:
+                print(f"warning: pool-fitted variant not timed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            fitted = None
+        bucket_graphs, bucket_of, bucket_padded = headline
+        if not all_ranks(fitted is not None):
+            fitted = None
 
     # the same step with the other operand precision of the dense products, timed the same way after the
     # headline measurement (reported beside it, never as ``value``)
@@ -444,18 +526,26 @@ def main():
                                   "into its static tensors" % (sum(1 for k, _ in graphed.segments if k == "graph"),
                                                                graphed.nodes.get("kernel", 0),
                                                                graphed.nodes.get("memcpy", 0))
-                                  + ("; %d recordings, one per %s of the pool (nodes %s)"
-                                     % (len(bucket_graphs), "distinct padded shape" if world == 1 else "batch",
-                                        [g.spec.num_nodes for g in bucket_graphs])
+                                  + ("; the pool's %d batches spread over %d recorded shapes (nodes %s, batches per shape %s)"
+                                     % (len(pool), len(bucket_graphs), [g.spec.num_nodes for g in bucket_graphs],
+                                        [bucket_of.count(j) for j in range(len(bucket_graphs))])
                                      if bucket_of is not None else ""))
                        if graphed is not None else (graph_note or "eager"),
                        "kernel_timing": "kernel time stamps of %d eager steps after the timed region" % args.steps
                        if graphed is not None else "kernel time stamps inside the timed region",
                        "discarded_steps": trainer.overflowed_steps(), "tuned": tuned,
+                       "pool": len(pool), "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else 0,
                        "capacities": None if spec is None else
-                       {"slack_over_largest_batch_of_the_pool": args.capacity_slack, "nodes": spec.num_nodes,
+                       {"slack_over_largest_batch": args.capacity_slack, "node_slack": min(args.capacity_slack, 1.05),
                         "largest_batch_nodes": max(int(b.num_nodes) for b, _ in pool),
-                        "filtered_edges_aa_al_interaction_aa_rows": list(spec.edge_capacity)},
+                        "smallest_batch_nodes": min(int(b.num_nodes) for b, _ in pool),
+                        "recorded_shapes": [{"nodes": g.spec.num_nodes, "batches": bucket_of.count(j),
+                                             "filtered_edges_aa_al_interaction_aa_rows": list(g.spec.edge_capacity)}
+                                            for j, g in enumerate(bucket_graphs)] if bucket_of is not None else
+                        [{"nodes": spec.num_nodes, "batches": len(pool),
+                          "filtered_edges_aa_al_interaction_aa_rows": list(spec.edge_capacity)}]},
+                       "tuned_to_pool_variant": fitted,
                        "precision": "fp32 throughout" if args.matmul == "fp32" else
                        "dense products on the bf16 matrix instructions with fp32 accumulation: forward products on "
                        "split (hi + lo) bf16 operands, gradient products on bf16 operands; attention, norms, "
@@ -471,8 +561,13 @@ def main():
                                         "note": "same step and schedule, dense products on "
                                                 + ("the bf16 matrix instructions (results within 2e-2)"
                                                    if other[0] == "bf16" else "fp32 operands")}
+        try:
+            al_rows = max((en["edges_per_launch"] for en in extra if en["caller"] == "ALEncoder"), default=0.0)
+            result["dense_roofline"] = dense_roofline(dev, int(al_rows) or 136_000, args.embed_dim, args.matmul)
+        except Exception as exc:  # noqa: BLE001 -- an extra object of the line
+            result["dense_roofline"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.embed_dim, args.cpu_scenes, args.cpu_steps)
+            result["cpu_baseline"] = cpu_baseline(args.embed_dim, args.cpu_scenes, args.cpu_steps, args.cpu_warmup)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -20,7 +20,7 @@ reference's offline preprocessor (``nuscenes_dataset.py:101-173,217-245,284-323`
 from __future__ import annotations
 
 import math
-from typing import Dict, Iterable, List, Optional
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 
@@ -339,6 +339,80 @@ class BatchSpec:
             e = max(e, int(b["edge_index"].shape[1]))
             la = max(la, int(b["lane_actor_index"].shape[1]))
         return BatchSpec(up(n + 1), up(l), up(e), up(la))
+
+    def key(self) -> tuple:
+        """All capacities as one tuple (equal keys: the same padded shape)."""
+        return (self.num_nodes, self.num_lanes, self.num_edges, self.num_lane_actor) + tuple(self.edge_capacity or ())
+
+    @staticmethod
+    def union(specs: Iterable["BatchSpec"]) -> "BatchSpec":
+        """The smallest spec that holds whatever any of ``specs`` holds (capacity by capacity the largest)."""
+        specs = list(specs)
+        caps = [s.edge_capacity for s in specs if s.edge_capacity is not None]
+        if caps and len(caps) != len(specs):
+            raise ValueError("either every spec carries filtered-edge capacities or none does")
+        return BatchSpec(max(s.num_nodes for s in specs), max(s.num_lanes for s in specs),
+                         max(s.num_edges for s in specs), max(s.num_lane_actor for s in specs),
+                         edge_capacity=tuple(max(c) for c in zip(*caps)) if caps else None)
+
+    def padded_work(self) -> int:
+        """What one step at this shape costs, up to a factor: the rows its kernels are launched over (padded rows
+        are computed like real ones) -- filtered agent-agent and lane-actor edges, whose per-edge work dominates
+        the step, plus the candidate lists the edge construction scans."""
+        if self.edge_capacity is None:
+            return self.num_nodes + self.num_edges + self.num_lane_actor
+        return sum(self.edge_capacity[:3]) + self.num_nodes + (self.num_edges + self.num_lane_actor) // 8
+
+    @staticmethod
+    def shape_buckets(specs: List["BatchSpec"], max_buckets: int = 4, merge_equal: bool = True
+                      ) -> Tuple[List["BatchSpec"], List[int]]:
+        """At most ``max_buckets`` shapes for batches whose own smallest shapes are ``specs``: returns the bucket
+        shapes and, for every entry of ``specs``, the index of its bucket (whose shape holds it).
+
+        A step recorded at a fixed shape computes every padded row, so a batch should run at the smallest recorded
+        shape that holds it; every recording costs memory and set-up time, so there are only a few.  The batches
+        are ordered by ``padded_work`` and cut into consecutive runs; the cuts minimise the summed
+        ``padded_work`` of the shapes the batches end up running at (dynamic programme over cut positions).
+        ``merge_equal`` False: exactly ``min(max_buckets, len(specs))`` buckets even if some come out equal (ranks
+        of a data-parallel job must all make the same number of recordings)."""
+        n = len(specs)
+        if n == 0:
+            return [], []
+        k = max(1, min(int(max_buckets), n))
+        order = sorted(range(n), key=lambda i: (specs[i].padded_work(), specs[i].key()))
+        cost = {}
+        for a in range(n):  # cost[a, b]: batches order[a:b] in one bucket
+            u = specs[order[a]]
+            for b in range(a + 1, n + 1):
+                u = BatchSpec.union([u, specs[order[b - 1]]])
+                cost[a, b] = (b - a) * u.padded_work()
+        inf = float("inf")
+        best = [[inf] * (n + 1) for _ in range(k + 1)]  # best[j][b]: first b batches in exactly j buckets
+        cut = [[0] * (n + 1) for _ in range(k + 1)]
+        best[0][0] = 0
+        for j in range(1, k + 1):
+            for b in range(j, n + 1):
+                for a in range(j - 1, b):
+                    c = best[j - 1][a] + cost[a, b]
+                    if c < best[j][b]:
+                        best[j][b], cut[j][b] = c, a
+        bounds, b = [], n
+        for j in range(k, 0, -1):
+            bounds.append((cut[j][b], b))
+            b = cut[j][b]
+        bounds.reverse()
+        shapes, bucket_of, seen = [], [0] * n, {}
+        for a, b in bounds:
+            u = BatchSpec.union([specs[i] for i in order[a:b]])
+            if merge_equal and u.key() in seen:
+                idx = seen[u.key()]
+            else:
+                idx = len(shapes)
+                shapes.append(u)
+                seen.setdefault(u.key(), idx)
+            for i in order[a:b]:
+                bucket_of[i] = idx
+        return shapes, bucket_of
 
     def __repr__(self) -> str:
         return (f"BatchSpec(num_nodes={self.num_nodes}, num_lanes={self.num_lanes}, num_edges={self.num_edges}, "

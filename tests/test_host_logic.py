@@ -261,3 +261,35 @@ def test_seed_scope_is_reproducible_and_nests():
     outside = ops._fresh_seed()
     torch.manual_seed(77)
     assert ops._fresh_seed() == outside
+
+
+def test_shape_buckets_hold_their_batches_and_beat_one_shape():
+    """``BatchSpec.shape_buckets``: every batch lands in a bucket whose shape holds it, the cuts never cost more
+    padded rows than one shape for all or than equal-count runs, and the number of buckets is what was asked for."""
+    import random
+    rng = random.Random(7)
+    specs = []
+    for _ in range(32):
+        n = rng.randint(1900, 3300)
+        up = lambda v, m: -(-v // m) * m  # noqa: E731
+        specs.append(hv.BatchSpec(up(n + 1, 64), up(3 * n, 64), up(30 * n + rng.randint(0, 900), 64), up(50 * n, 64),
+                                  edge_capacity=(up(25 * n, 256), up(48 * n + rng.randint(0, 5000), 256), up(18 * n, 256),
+                                                 up(10 * n, 256))))
+    shapes, which = hv.BatchSpec.shape_buckets(specs, 4)
+    assert len(shapes) == 4 and len(which) == 32 and set(which) == {0, 1, 2, 3}
+    for sp, j in zip(specs, which):
+        assert all(a <= b for a, b in zip(sp.key(), shapes[j].key()))
+    cost = sum(shapes[j].padded_work() for j in which)
+    one = 32 * hv.BatchSpec.union(specs).padded_work()
+    order = sorted(range(32), key=lambda i: specs[i].padded_work())
+    quartiles = sum(8 * hv.BatchSpec.union([specs[i] for i in order[a:a + 8]]).padded_work() for a in range(0, 32, 8))
+    assert cost <= quartiles < one
+    assert cost >= sum(sp.padded_work() for sp in specs)
+    # fewer batches than buckets; equal shapes merge unless every rank must make the same number of recordings
+    shapes, which = hv.BatchSpec.shape_buckets(specs[:2], 4)
+    assert len(shapes) == 2 and sorted(which) == [0, 1]
+    shapes, which = hv.BatchSpec.shape_buckets([specs[0]] * 5, 4)
+    assert len(shapes) == 1 and which == [0] * 5
+    shapes, which = hv.BatchSpec.shape_buckets([specs[0]] * 5, 4, merge_equal=False)
+    assert len(shapes) == 4 and sorted(set(which)) == [0, 1, 2, 3]
+    assert hv.BatchSpec.shape_buckets([], 4) == ([], [])
