@@ -99,9 +99,10 @@ SIGNATURES = {
     "hivt_weighted_mean_fwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_weighted_mean_bwd": (c_int, [_P, _P, _P, c_int64, c_float, _P, _P]),
     "hivt_batch_prepare": (c_int, [_P, _P, _P, c_int64, c_int64, _P, c_int64, _P, _P, _P, c_int32, c_int32, c_int32,
-                                   c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                   c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "hivt_row_subset_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "hivt_row_subset": (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, c_int64, _P, c_int64, _P,
-                                _P, _P, _P, _P, _P, _P]),
+                                _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_center_rows": (c_int, [_P, _P, c_int64, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
     "hivt_rows_put_tokens": (c_int, [_P, c_int64, _P, _P, c_int64, c_int32, c_int32, _P, _P]),
     "hivt_temporal_input_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),

@@ -269,32 +269,68 @@ struct ScaleRows {
   int32_t count;
 };
 
-__global__ __launch_bounds__(256) void hinge_r1_multi_fwd_kernel(const ScaleRows p, const float* __restrict__ w,
-                                                                 const float* __restrict__ count, int64_t B, float lambda,
-                                                                 float* __restrict__ out) {
-  __shared__ float red[256];
+// Sums of K values per thread over a workgroup of kLossThreads threads, in a fixed order: xor-shuffle tree inside
+// every wave, then the waves' sums added in wave order.  One barrier pair per call.
+constexpr int kLossThreads = 1024;
+
+template <int K>
+__device__ __forceinline__ void block_sums(float (&v)[K], float (*smem)[K]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) smem[wave][k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float t = smem[0][k];
+    for (int w = 1; w < kLossThreads / 64; ++w) t += smem[w][k];
+    v[k] = t;
+  }
+  __syncthreads();
+}
+
+// The number of kept rows: the caller's device scalar, or max(sum of w, 1) computed here.
+__device__ __forceinline__ float kept_rows(const float* __restrict__ count, const float* __restrict__ w, int64_t B,
+                                           float (*smem)[1]) {
+  if (count != nullptr) return *count;
+  float c[1] = {0.0f};
+  for (int64_t i = threadIdx.x; i < B; i += kLossThreads) c[0] += w[i];
+  block_sums<1>(c, smem);
+  return fmaxf(c[0], 1.0f);
+}
+
+// out[0] = sum_k loss_k, out[1 + 2k] = loss_k, out[2 + 2k] = r1_k, out[1 + 2K] = the number of kept rows
+__global__ __launch_bounds__(kLossThreads) void hinge_r1_multi_fwd_kernel(const ScaleRows p, const float* __restrict__ w,
+                                                                          const float* __restrict__ count, int64_t B,
+                                                                          float lambda, float* __restrict__ out) {
+  __shared__ float smem3[kLossThreads / 64][3];
+  __shared__ float smem1[kLossThreads / 64][1];
+  const float cnt = kept_rows(count, w, B, smem1);
   float total = 0.0f;
   for (int k = 0; k < p.count; ++k) {
-    float a = 0.0f, b = 0.0f, c = 0.0f;
-    for (int64_t i = threadIdx.x; i < B; i += 256) {
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    for (int64_t i = threadIdx.x; i < B; i += kLossThreads) {
       const float wi = w[i];
-      a += fmaxf(1.0f - p.s_real[k][i], 0.0f) * wi;
-      b += fmaxf(1.0f + p.s_fake[k][i], 0.0f) * wi;
-      c += p.grad_norm2[k][i] * wi;
+      v[0] += fmaxf(1.0f - p.s_real[k][i], 0.0f) * wi;
+      v[1] += fmaxf(1.0f + p.s_fake[k][i], 0.0f) * wi;
+      v[2] += p.grad_norm2[k][i] * wi;
     }
-    a = block_sum_256(a, red);
-    b = block_sum_256(b, red);
-    c = block_sum_256(c, red);
-    const float cnt = *count;
-    const float r1 = c / cnt;
-    const float loss = (a / cnt + b / cnt) + lambda * r1;
+    block_sums<3>(v, smem3);
+    const float r1 = v[2] / cnt;
+    const float loss = (v[0] / cnt + v[1] / cnt) + lambda * r1;
     total = k == 0 ? loss : total + loss;
     if (threadIdx.x == 0) {
       out[1 + 2 * k] = loss;
       out[2 + 2 * k] = r1;
     }
   }
-  if (threadIdx.x == 0) out[0] = total;
+  if (threadIdx.x == 0) {
+    out[0] = total;
+    out[1 + 2 * p.count] = cnt;
+  }
 }
 
 __global__ __launch_bounds__(256) void hinge_r1_multi_bwd_kernel(const ScaleRows p, const float* __restrict__ g_loss,
@@ -310,25 +346,34 @@ __global__ __launch_bounds__(256) void hinge_r1_multi_bwd_kernel(const ScaleRows
 }
 
 // Generator objective (models/hivt.py:317-324 with losses/adv_losses.py:91-98): out[0] = (losses[0] + losses[1]) +
-// out[1], out[1] = lambda_adv * sum_k out[2 + k], out[2 + k] = -sum_i w_i s_k[i] / count.  One block.
-__global__ __launch_bounds__(256) void generator_total_fwd_kernel(const ScaleRows p, const float* __restrict__ losses,
-                                                                  const float* __restrict__ w,
-                                                                  const float* __restrict__ count, int64_t B,
-                                                                  float lambda_adv, float* __restrict__ out) {
-  __shared__ float red[256];
-  float total = 0.0f;
-  for (int k = 0; k < p.count; ++k) {
-    float a = 0.0f;
-    for (int64_t i = threadIdx.x; i < B; i += 256) a += p.s_fake[k][i] * w[i];
-    a = block_sum_256(a, red);
-    const float g = -1.0f * (a / *count);
-    total = k == 0 ? g : total + g;
-    if (threadIdx.x == 0) out[2 + k] = g;
+// out[1], out[1] = lambda_adv * sum_k out[2 + k], out[2 + k] = -sum_i w_i s_k[i] / count, out[2 + K] = the number
+// of kept rows.  One workgroup.
+__global__ __launch_bounds__(kLossThreads) void generator_total_fwd_kernel(const ScaleRows p, const float* __restrict__ losses,
+                                                                           const float* __restrict__ w,
+                                                                           const float* __restrict__ count, int64_t B,
+                                                                           float lambda_adv, float* __restrict__ out) {
+  __shared__ float smem4[kLossThreads / 64][kMaxScales];
+  __shared__ float smem1[kLossThreads / 64][1];
+  const float cnt = kept_rows(count, w, B, smem1);
+  float v[kMaxScales] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int64_t i = threadIdx.x; i < B; i += kLossThreads) {
+    const float wi = w[i];
+#pragma unroll
+    for (int k = 0; k < kMaxScales; ++k)
+      if (k < p.count) v[k] += p.s_fake[k][i] * wi;
   }
+  block_sums<kMaxScales>(v, smem4);
   if (threadIdx.x == 0) {
+    float total = 0.0f;
+    for (int k = 0; k < p.count; ++k) {
+      const float g = -1.0f * (v[k] / cnt);
+      total = k == 0 ? g : total + g;
+      out[2 + k] = g;
+    }
     const float adv = lambda_adv * total;
     out[1] = adv;
     out[0] = (losses[0] + losses[1]) + adv;
+    out[2 + p.count] = cnt;
   }
 }
 
@@ -807,14 +852,15 @@ extern "C" int hivt_hinge_r1_multi_fwd(const float* const* s_real, const float* 
                                        int64_t B, float lambda_r1, float* out, hivt_stream_t stream) {
   const char* what = "hivt_hinge_r1_multi_fwd";
   HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
-  HIVT_REQUIRE(count && out && s_real && grad_norm2 && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(out && s_real && grad_norm2 && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
   ScaleRows p{};
   p.count = scales;
   for (int k = 0; k < scales; ++k) {
     HIVT_REQUIRE(B == 0 || (s_real[k] && grad_norm2[k] && s_fake[k]), HIVT_ERR_ARG, "%s: null rows (scale %d)", what, k);
     p.s_real[k] = s_real[k]; p.grad_norm2[k] = grad_norm2[k]; p.s_fake[k] = s_fake[k];
   }
-  hipLaunchKernelGGL(hinge_r1_multi_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, w, count, B, lambda_r1, out);
+  hipLaunchKernelGGL(hinge_r1_multi_fwd_kernel, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, p, w, count, B,
+                     lambda_r1, out);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }
@@ -847,15 +893,15 @@ extern "C" int hivt_generator_total_fwd(const float* losses, const float* const*
                                         hivt_stream_t stream) {
   const char* what = "hivt_generator_total_fwd";
   HIVT_REQUIRE(B >= 0 && scales >= 1 && scales <= kMaxScales, HIVT_ERR_ARG, "%s: 1..%d scales", what, kMaxScales);
-  HIVT_REQUIRE(losses && count && out && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
+  HIVT_REQUIRE(losses && out && s_fake && (B == 0 || w), HIVT_ERR_ARG, "%s: null pointer", what);
   ScaleRows p{};
   p.count = scales;
   for (int k = 0; k < scales; ++k) {
     HIVT_REQUIRE(B == 0 || s_fake[k], HIVT_ERR_ARG, "%s: null rows (scale %d)", what, k);
     p.s_fake[k] = s_fake[k];
   }
-  hipLaunchKernelGGL(generator_total_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, losses, w, count, B,
-                     lambda_adv, out);
+  hipLaunchKernelGGL(generator_total_fwd_kernel, dim3(1), dim3(kLossThreads), 0, (hipStream_t)stream, p, losses, w, count,
+                     B, lambda_adv, out);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

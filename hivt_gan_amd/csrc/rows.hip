@@ -38,7 +38,6 @@ struct PrepareArgs {
   float* x_steps;           // [T * N, 2]: x itself in that row order
   int32_t* lane_code;       // [L]
   float* keep_w;            // [N]
-  float* keep_count;        // [1]
 };
 
 // row vector (a, b) times [[c, -s], [s, c]], products and sum rounded separately (as the framework's
@@ -57,7 +56,6 @@ __device__ __forceinline__ bool any_future(const PrepareArgs& a, int n) {
 }
 
 __global__ __launch_bounds__(256) void batch_prepare_kernel(const PrepareArgs a) {
-  __shared__ float red[256];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < a.N) {
     const float ang = a.angles[i];
@@ -81,17 +79,6 @@ __global__ __launch_bounds__(256) void batch_prepare_kernel(const PrepareArgs a)
     *reinterpret_cast<float2*>(a.y_rot + 2 * i) = rotate_row(v.x, v.y, c, s);
   }
   if (i < a.L) a.lane_code[i] = ((int)a.is_int[i] * 3 + (int)a.turn[i]) * 2 + (int)a.ctrl[i];
-  if (blockIdx.x == 0) {  // number of agents with a future step, at least one; fixed order of sums
-    float cnt = 0.0f;
-    for (int n = threadIdx.x; n < a.N; n += 256) cnt += any_future(a, n) ? 1.0f : 0.0f;
-    red[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int half = 128; half > 0; half >>= 1) {
-      if ((int)threadIdx.x < half) red[threadIdx.x] += red[threadIdx.x + half];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) a.keep_count[0] = fmaxf(red[0], 1.0f);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -117,62 +104,105 @@ __device__ __forceinline__ int node_valid(const SubsetArgs& a, int64_t m) {
   return a.pm[n * a.pm_stride + t] == 0 ? 1 : 0;
 }
 
-// One block: inclusive count of valid nodes up to each node (left in new_id), the total and the first valid node.
-__global__ __launch_bounds__(1024) void subset_scan_kernel(const SubsetArgs a) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
+// Two launches.  (1) every workgroup counts the valid nodes among its 256; (2) every workgroup adds up the counts of
+// the workgroups before it (a few hundred values), ranks its own nodes with wave ballots and fills its share of the
+// outputs; the last workgroup also writes the total, the tail of the packed arrays and the overflow flag.
+constexpr int kSubsetThreads = 256;
+
+__global__ __launch_bounds__(kSubsetThreads) void subset_count_kernel(const SubsetArgs a, int32_t* __restrict__ block_counts) {
+  __shared__ int wave_tot[kSubsetThreads / kWave];
   const int64_t M = (int64_t)a.N * a.T;
-  const int64_t per = (M + 1023) / 1024;
-  const int64_t lo = (int64_t)tid * per;
-  const int64_t hi = lo + per < M ? lo + per : M;
-  int s = 0;
-  for (int64_t m = lo; m < hi; ++m) s += node_valid(a, m);
-  part[tid] = s;
+  const int64_t m = (int64_t)blockIdx.x * kSubsetThreads + threadIdx.x;
+  const int v = m < M ? node_valid(a, m) : 0;
+  const int w = __popcll(__ballot(v != 0));
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = w;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = tid >= o ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = tid == 0 ? 0 : part[tid - 1];
-  for (int64_t m = lo; m < hi; ++m) {
-    const int v = node_valid(a, m);
-    if (v && run == 0) a.count[1] = (int32_t)m;
-    run += v;
-    a.new_id[m] = run;
-  }
-  if (tid == 1023) {
-    a.count[0] = part[1023];
-    if (part[1023] == 0) a.count[1] = (int32_t)(M > 0 ? M - 1 : 0);
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kSubsetThreads / kWave; ++k) s += wave_tot[k];
+    block_counts[blockIdx.x] = s;
   }
 }
 
-__global__ __launch_bounds__(256) void subset_fill_kernel(const SubsetArgs a) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(kSubsetThreads) void subset_fill_kernel(const SubsetArgs a, const int32_t* __restrict__ block_counts,
+                                                                     int32_t blocks) {
+  __shared__ int red[kSubsetThreads / kWave];
+  __shared__ int wave_tot[kSubsetThreads / kWave];
+  __shared__ int s_first;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t M = (int64_t)a.N * a.T;
-  const int32_t count = a.count[0];
-  const int32_t packed = count < a.capacity ? count : a.capacity;
-  if (i < M) {
-    const int32_t p = a.new_id[i] - 1;
-    if (node_valid(a, i) && p < a.capacity) {
-      a.rows[p] = (int32_t)i;
-      if (a.packed_rowptr != nullptr) a.packed_rowptr[p] = a.rowptr[i];
+  // nodes before this workgroup, and (last workgroup) all nodes
+  int before = 0, total = 0;
+  for (int b = threadIdx.x; b < blocks; b += kSubsetThreads) {
+    const int c = block_counts[b];
+    total += c;
+    if (b < (int)blockIdx.x) before += c;
+  }
+  before = wave_sum_i(before);
+  total = wave_sum_i(total);
+  if (lane == 0) { red[wave] = before; wave_tot[wave] = total; }
+  __syncthreads();
+  before = 0; total = 0;
+#pragma unroll
+  for (int k = 0; k < kSubsetThreads / kWave; ++k) { before += red[k]; total += wave_tot[k]; }
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * kSubsetThreads + threadIdx.x;
+  const int v = m < M ? node_valid(a, m) : 0;
+  const unsigned long long ballot = __ballot(v != 0);
+  const int lane_rank = __popcll(ballot & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = __popcll(ballot);
+  __syncthreads();
+  int wave_off = 0;
+#pragma unroll
+  for (int k = 0; k < kSubsetThreads / kWave; ++k)
+    if (k < wave) wave_off += wave_tot[k];
+  if (m < M) {
+    const int32_t p = before + wave_off + lane_rank - (v ? 0 : 1);  // position of the last valid node up to m
+    if (v && p < a.capacity) {
+      a.rows[p] = (int32_t)m;
+      if (a.packed_rowptr != nullptr) a.packed_rowptr[p] = a.rowptr[m];
     }
-    a.new_id[i] = p < 0 ? 0 : (p < a.capacity ? p : a.capacity - 1);
+    if (v && p == 0) a.count[1] = (int32_t)m;  // the first valid node
+    a.new_id[m] = p < 0 ? 0 : (p < a.capacity ? p : a.capacity - 1);
   }
-  if (i < a.capacity) {
-    a.live[i] = i < count ? 1 : 0;
-    if (i >= packed) a.rows[i] = a.count[1];  // a valid node id: gathers through it stay finite
-  }
-  if (a.packed_rowptr != nullptr && i >= packed && i <= a.capacity) a.packed_rowptr[i] = a.rowptr[M];
-  if (i == 0) {
-    bool over = count > a.capacity;
+  if ((int)blockIdx.x == blocks - 1 && threadIdx.x == 0) {  // totals and flags
+    a.count[0] = total;
+    if (total == 0) a.count[1] = (int32_t)(M > 0 ? M - 1 : 0);
+    bool over = total > a.capacity;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (a.edge_count[k] != nullptr) over |= (int64_t)*a.edge_count[k] > a.edge_cap[k];
     a.overflow[0] = over ? 1 : 0;
+    if (a.packed_rowptr != nullptr) a.packed_rowptr[a.capacity] = a.rowptr[M];  // the end of the last packed row
   }
+  // this workgroup's slice of the packed arrays: the live flags, and behind the live rows a valid node id (gathers
+  // through it stay finite) and the end of the edge list
+  const int packed = total < a.capacity ? total : a.capacity;
+  const int64_t i = m;  // capacity <= M, so the slices of all workgroups cover [0, capacity)
+  const bool tail_here = (int64_t)blockIdx.x * kSubsetThreads + kSubsetThreads > packed &&
+                         (int64_t)blockIdx.x * kSubsetThreads <= a.capacity;
+  if (!tail_here) {
+    if (i < a.capacity) a.live[i] = 1;
+    return;
+  }
+  if (threadIdx.x == 0) {  // id of the first valid node: its workgroup from the counts, then its nodes one by one
+    int first = (int)(M > 0 ? M - 1 : 0);
+    for (int b = 0; b < blocks; ++b) {
+      if (block_counts[b] > 0) {
+        for (int64_t q = (int64_t)b * kSubsetThreads; q < M; ++q)
+          if (node_valid(a, q)) { first = (int)q; break; }
+        break;
+      }
+    }
+    s_first = first;
+  }
+  __syncthreads();
+  if (i < a.capacity) {
+    a.live[i] = i < total ? 1 : 0;
+    if (i >= packed) a.rows[i] = s_first;
+  }
+  if (a.packed_rowptr != nullptr && i >= packed && i < a.capacity) a.packed_rowptr[i] = a.rowptr[M];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,10 +448,9 @@ extern "C" int hivt_batch_prepare(const float* rotate_angles, const float* y, co
                                   const uint8_t* is_intersections, const uint8_t* turn_directions,
                                   const uint8_t* traffic_controls, int32_t N, int32_t T, int32_t Hf, int32_t L,
                                   float* rotate_mat, float* y_rot, float* x_rot, float* x_steps, int32_t* lane_code,
-                                  float* keep_w, float* keep_count, hivt_stream_t stream) {
+                                  float* keep_w, hivt_stream_t stream) {
   const char* what = "hivt_batch_prepare";
   HIVT_REQUIRE(N >= 0 && T > 0 && Hf >= 0 && L >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
-  HIVT_REQUIRE(keep_count != nullptr, HIVT_ERR_ARG, "%s: keep_count is null", what);
   HIVT_REQUIRE(N == 0 || (rotate_angles && x && padding_mask && rotate_mat && x_rot && x_steps && keep_w), HIVT_ERR_ARG,
                "%s: null pointer", what);
   HIVT_REQUIRE(y == nullptr || y_rot != nullptr, HIVT_ERR_ARG, "%s: y without y_rot", what);
@@ -437,7 +466,6 @@ extern "C" int hivt_batch_prepare(const float* rotate_angles, const float* y, co
   a.is_int = is_intersections; a.turn = turn_directions; a.ctrl = traffic_controls;
   a.N = N; a.T = T; a.Hf = Hf; a.L = L;
   a.rot = rotate_mat; a.y_rot = y_rot; a.x_rot = x_rot; a.x_steps = x_steps; a.lane_code = lane_code; a.keep_w = keep_w;
-  a.keep_count = keep_count;
   int64_t items = (int64_t)N * (T > Hf ? T : Hf);
   if (items < L) items = L;
   if (items < N) items = N;
@@ -447,13 +475,20 @@ extern "C" int hivt_batch_prepare(const float* rotate_angles, const float* y, co
   return HIVT_OK;
 }
 
+extern "C" size_t hivt_row_subset_workspace_bytes(int32_t N, int32_t T) {
+  const int64_t blocks = ((int64_t)(N > 0 ? N : 0) * (T > 0 ? T : 0) + kSubsetThreads - 1) / kSubsetThreads;
+  return align_up((size_t)(blocks > 0 ? blocks : 1) * sizeof(int32_t), 256);
+}
+
 extern "C" int hivt_row_subset(const uint8_t* padding_mask, int64_t pm_stride, int32_t N, int32_t T, int32_t capacity,
                                const int32_t* rowptr, const int32_t* edge_count0, int64_t edge_cap0,
                                const int32_t* edge_count1, int64_t edge_cap1, const int32_t* edge_count2,
                                int64_t edge_cap2, int32_t* rows, int32_t* new_id, uint8_t* live, int32_t* count,
-                               int32_t* packed_rowptr, uint8_t* overflow, hivt_stream_t stream) {
+                               int32_t* packed_rowptr, uint8_t* overflow, void* workspace, size_t workspace_bytes,
+                               hivt_stream_t stream) {
   const char* what = "hivt_row_subset";
-  HIVT_REQUIRE(N > 0 && T > 0 && capacity > 0 && (int64_t)N * T < ((int64_t)1 << 31), HIVT_ERR_ARG, "%s: bad sizes", what);
+  HIVT_REQUIRE(N > 0 && T > 0 && capacity > 0 && (int64_t)N * T < ((int64_t)1 << 31) && capacity <= (int64_t)N * T,
+               HIVT_ERR_ARG, "%s: bad sizes (the capacity is at most N * T)", what);
   HIVT_REQUIRE(padding_mask && rows && new_id && live && count && overflow, HIVT_ERR_ARG, "%s: null pointer", what);
   HIVT_REQUIRE(pm_stride >= T, HIVT_ERR_ARG, "%s: padding_mask rows shorter than T", what);
   HIVT_REQUIRE((rowptr == nullptr) == (packed_rowptr == nullptr), HIVT_ERR_ARG,
@@ -465,11 +500,13 @@ extern "C" int hivt_row_subset(const uint8_t* padding_mask, int64_t pm_stride, i
   a.rows = rows; a.new_id = new_id; a.live = live; a.count = count; a.packed_rowptr = packed_rowptr;
   a.overflow = overflow;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(subset_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+  const int32_t blocks = (int32_t)(((int64_t)N * T + kSubsetThreads - 1) / kSubsetThreads);
+  HIVT_REQUIRE(workspace != nullptr && workspace_bytes >= hivt_row_subset_workspace_bytes(N, T), HIVT_ERR_WORKSPACE,
+               "%s: workspace too small", what);
+  int32_t* block_counts = reinterpret_cast<int32_t*>(workspace);
+  hipLaunchKernelGGL(subset_count_kernel, dim3((unsigned)blocks), dim3(kSubsetThreads), 0, s, a, block_counts);
   HIVT_CHECK_LAUNCH(what);
-  int64_t items = (int64_t)N * T;
-  if (items < (int64_t)capacity + 1) items = (int64_t)capacity + 1;
-  hipLaunchKernelGGL(subset_fill_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(subset_fill_kernel, dim3((unsigned)blocks), dim3(kSubsetThreads), 0, s, a, block_counts, blocks);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

@@ -12,8 +12,10 @@ A data-parallel step is recorded in segments: the gradient all-reduces run eager
 payloads are 1.5 MB and 10 MB, a fraction of a millisecond on xGMI, so what matters for scaling is that
 the ranks stay GPU-bound, not that the collectives hide behind the backward pass).
 
-What a recorded step fixes until it is recorded again: the learning rate (``GanTrainer.end_epoch``
-invalidates the recording), the critic-stream schedule, the batch shapes (``BatchSpec``).
+What a recorded step fixes until it is recorded again: the critic-stream schedule and the batch shapes
+(``BatchSpec``).  The learning rate is not among them: the library's AdamW kernel reads it from a device scalar that
+``run`` refreshes before every replay (``FusedAdamW.sync_lr``); only a recording whose update went through the
+framework's kernel (the rate is a launch argument there) is recorded again when the rate changes.
 """
 from __future__ import annotations
 
@@ -187,14 +189,63 @@ class GraphedStep:
         self.segments.append(("call", fn))
         self._begin_segment()
 
+    def _snapshot(self):
+        """Copies of everything a training step changes: parameters, buffers (the critics' power-iteration
+        vectors), optimizer state, the dropout seed and the overflow counter."""
+        t = self.trainer
+        tensors = list(t.model.parameters()) + list(t.model.buffers())
+        saved = [(x, x.detach().clone()) for x in tensors]
+        seen = {id(x) for x in tensors}
+        known = []
+        for opt in (t.opt_g, t.opt_d):
+            if opt is None:
+                continue
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v) and id(v) not in seen:
+                        seen.add(id(v))
+                        saved.append((v, v.detach().clone()))
+                        known.append(id(v))
+        saved.append((self.seed, self.seed.clone()))
+        overflows = t._overflows.clone() if t._overflows is not None else None
+        return saved, set(known), overflows
+
+    def _restore(self, snapshot) -> None:
+        saved, known, overflows = snapshot
+        t = self.trainer
+        with torch.no_grad():
+            for x, copy in saved:
+                x.copy_(copy)
+            # optimizer state that the warm-up steps created starts from zero, as a first step would find it
+            fresh = {}
+            for opt in (t.opt_g, t.opt_d):
+                if opt is None:
+                    continue
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v) and id(v) not in known:
+                            fresh[id(v)] = v
+            for v in fresh.values():
+                v.zero_()
+            if t._overflows is not None:
+                if overflows is not None:
+                    t._overflows.copy_(overflows)
+                else:
+                    t._overflows.zero_()
+
     def record(self) -> None:
         """(Re)records the step: ``warmup`` eager steps on the recording stream (allocator, optimizer
-        state, autograd nodes settle there), then one step under capture."""
+        state, autograd nodes settle there), then one step under capture.  The warm-up steps run on whatever the
+        static inputs hold, so what they changed -- parameters, optimizer state, power-iteration vectors, the
+        dropout seed, the overflow counter -- is put back afterwards: recording leaves the training state as it
+        found it (the capture itself executes nothing)."""
+        snapshot = self._snapshot()
         current = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(current)
         with torch.cuda.stream(self._stream):
             for _ in range(self.warmup):
                 self._one_step()
+            self._restore(snapshot)
         current.wait_stream(self._stream)
         torch.cuda.synchronize(self.device)
         self.segments = []
@@ -227,6 +278,9 @@ class GraphedStep:
                 g.instantiate()
         self._lr = [g["lr"] for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None
                     for g in opt.param_groups]
+        # every update of the recording went through the library's kernel, which reads the rate from device memory
+        opts = [opt for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None]
+        self._lr_on_device = all(getattr(opt, "last_step_on_library", False) for opt in opts)
 
     def load(self, batch: TemporalData) -> None:
         """Copies a batch padded to the same ``BatchSpec`` into the static inputs: one copy for a batch that
@@ -246,8 +300,11 @@ class GraphedStep:
 
     def run(self, batch: Optional[TemporalData] = None) -> Dict[str, torch.Tensor]:
         """One step; returns the recording's loss tensors (overwritten by the next replay)."""
+        for opt in (self.trainer.opt_g, self.trainer.opt_d):
+            if opt is not None and hasattr(opt, "sync_lr"):
+                opt.sync_lr()  # the recorded update reads its learning rate from a device scalar
         lr = [g["lr"] for opt in (self.trainer.opt_g, self.trainer.opt_d) if opt is not None for g in opt.param_groups]
-        if lr != self._lr:  # the learning rate is a launch argument of the recorded update
+        if lr != self._lr and not self._lr_on_device:  # a launch argument of the recorded update: record again
             self.record()
         if batch is not None:
             self.load(batch)

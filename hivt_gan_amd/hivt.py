@@ -258,11 +258,18 @@ class HiVT(nn.Module):
             if overflow is not None:
                 bad = bad | overflow
         logs = self._losses_and_updates(data, y_hat, pi, opt_g, opt_d, sync_grads, bad)
-        logs["skipped"] = bad.float()
+        if "skipped" not in logs:
+            logs["skipped"] = bad.float()
         return logs
 
     def _losses_and_updates(self, data, y_hat, pi, opt_g, opt_d, sync_grads, bad) -> Dict[str, torch.Tensor]:
         found_inf = bad.float() if bad is not None else None
+
+        def backward(loss: torch.Tensor) -> None:
+            if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+                loss.backward(ops.unit_scalar(loss))  # (a cached one: no fill per backward pass)
+            else:
+                loss.backward()
 
         def arm(group: str) -> None:
             # a data-parallel reducer that overlaps its collectives with the backward pass wants to know
@@ -302,7 +309,7 @@ class HiVT(nn.Module):
             loss = packed[0] + packed[1] if packed is not None else reg_loss + cls_loss
             opt_g.zero_grad(set_to_none=True)
             arm("generator")
-            loss.backward()
+            backward(loss)
             update("generator", opt_g, clip=True)
             logs["loss"] = loss.detach()
             return logs
@@ -310,8 +317,13 @@ class HiVT(nn.Module):
         prep = data.get("_prep")
         if packed is not None:
             real = data["y"]
-            if prep is not None:
-                keep, w, cnt = None, prep["keep_w"], prep["keep_count"]
+            fused_losses = len(self.critics) <= 4 and multi_supported(self.critics.values(), real, fake)
+            if prep is not None and fused_losses:
+                # (the fused objectives count the kept rows themselves)
+                keep, w, cnt = None, prep["keep_w"], None
+            elif prep is not None:
+                keep, w = None, prep["keep_w"]
+                cnt = w.sum().clamp(min=1.0)
             else:
                 keep = (~data["padding_mask"][:, self.historical_steps:]).any(dim=1)
                 w = keep.to(real.dtype)
@@ -324,7 +336,7 @@ class HiVT(nn.Module):
             d_loss, d_logs = self.d_loss_fn.forward_masked(self.critics, real, fake, keep, w, cnt)
             opt_d.zero_grad(set_to_none=True)
             arm("critic")
-            d_loss.backward()
+            backward(d_loss)
             if real.is_cuda:
                 join_critic_streams(real.device)
             update("critic", opt_d)
@@ -340,7 +352,7 @@ class HiVT(nn.Module):
                 g_total = (packed[0] + packed[1] if packed is not None else reg_loss + cls_loss) + g_adv
             opt_g.zero_grad(set_to_none=True)
             arm("generator")
-            g_total.backward()
+            backward(g_total)
             if fake.is_cuda:
                 join_critic_streams(fake.device)
         finally:
@@ -348,6 +360,8 @@ class HiVT(nn.Module):
                 p.requires_grad_(True)
         update("generator", opt_g)
         logs.update({"d_loss": d_loss.detach(), "g_adv": g_adv.detach(), "g_total": g_total.detach()})
+        if found_inf is not None:
+            logs["skipped"] = found_inf
         logs.update(d_logs)
         logs.update(g_logs)
         return logs

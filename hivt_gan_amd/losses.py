@@ -132,8 +132,10 @@ class AdversarialDiscriminatorLoss(nn.Module):
         Valid because every term is a per-sample mean and the critics act row-wise.  ``weights`` / ``count``: the
         keep mask as floats and the number of kept rows (at least 1), if the caller has them already."""
         w = weights if weights is not None else keep.to(real.dtype)
-        cnt = count if count is not None else w.sum().clamp(min=1.0)
         real, fake = real.detach(), fake.detach()
+        fused = multi_supported(critics.values(), real, fake) and len(critics) <= 4
+        # (the fused objective counts the kept rows itself when it is not handed their number)
+        cnt = count if (count is not None or fused) else w.sum().clamp(min=1.0)
 
         def one(name, critic):
             # score and ||d score / d input||^2 of the real samples come from ONE critic call, as in the
@@ -185,7 +187,7 @@ class AdversarialGeneratorLoss(nn.Module):
         return self.lambda_adv * total, logs
 
     def total_masked(self, critics: dict, fake: torch.Tensor, supervised: torch.Tensor, weights: torch.Tensor,
-                     count: torch.Tensor):
+                     count: Optional[torch.Tensor] = None):
         """``(g_total, g_adv, logs)`` with ``g_total = (supervised[0] + supervised[1]) + g_adv``
         (``models/hivt.py:317-324``): the critics' passes in one library call and the objective with all of its
         parts in one launch.  ``supervised`` = (regression, classification) loss as one tensor [2]; ``weights`` /

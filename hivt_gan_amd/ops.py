@@ -2254,8 +2254,24 @@ def step_guards(nan_check: Optional[torch.Tensor], finite_check: Optional[torch.
 # Row bookkeeping of a batch in single launches (hivt_gan_amd/csrc/rows.hip)
 # --------------------------------------------------------------------------------------------
 def _u8(t: torch.Tensor) -> torch.Tensor:
-    t = t.contiguous()
+    """A bool / uint8 tensor as uint8 whose last dimension is contiguous (a column slice of a 2-D mask stays a view:
+    the kernels take the row stride)."""
+    if not (t.dim() == 2 and t.stride(1) == 1):
+        t = t.contiguous()
     return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+_unit_scalars = {}
+
+
+def unit_scalar(ref: torch.Tensor) -> torch.Tensor:
+    """A cached 0-d float32 one on ``ref``'s device: the seed gradient of a backward pass (``loss.backward(unit)``)
+    without the fill that ``backward()`` issues for it on every call."""
+    key = str(ref.device)
+    t = _unit_scalars.get(key)
+    if t is None:
+        t = _unit_scalars[key] = torch.ones((), dtype=torch.float32, device=ref.device)
+    return t
 
 
 def batch_prepare_supported(data, historical_steps: int) -> bool:
@@ -2276,8 +2292,8 @@ def batch_prepare_supported(data, historical_steps: int) -> bool:
 def batch_prepare(data, historical_steps: int) -> dict:
     """Everything the step derives from the raw batch before the first layer, in one launch: ``rotate_mat``
     [N, 2, 2], the targets rotated into the agents' frames (``y``, or None), ``x_rot`` [T * N, 2] (step-major rotated
-    displacements; ``x_steps``: the un-rotated ones in the same order), ``lane_code`` int32 [L], ``keep_w`` [N] (1 where an agent has a valid future step) and
-    ``keep_count`` (device scalar: their number, at least 1)."""
+    displacements; ``x_steps``: the un-rotated ones in the same order), ``lane_code`` int32 [L] and ``keep_w`` [N] (1
+    where an agent has a valid future step)."""
     x = data["x"]
     n = int(x.shape[0])
     T = int(historical_steps)
@@ -2302,12 +2318,10 @@ def batch_prepare(data, historical_steps: int) -> dict:
     x_steps = torch.empty(T * n, 2, dtype=torch.float32, device=dev)
     lane_code = torch.empty(num_lanes, dtype=torch.int32, device=dev)
     keep_w = torch.empty(n, dtype=torch.float32, device=dev)
-    keep_count = torch.empty((), dtype=torch.float32, device=dev)
     _lib.call("hivt_batch_prepare", _p(ang), _p(y), _p(x), x.stride(0), x.stride(1), _p(pm), pm.stride(0), _p(lanes[0]),
               _p(lanes[1]), _p(lanes[2]), n, T, hf, num_lanes, _p(rot), _p(y_rot), _p(x_rot), _p(x_steps), _p(lane_code),
-              _p(keep_w), _p(keep_count), _stream(x))
-    return {"rotate_mat": rot, "y": y_rot, "x_rot": x_rot, "x_steps": x_steps, "lane_code": lane_code, "keep_w": keep_w,
-            "keep_count": keep_count}
+              _p(keep_w), _stream(x))
+    return {"rotate_mat": rot, "y": y_rot, "x_rot": x_rot, "x_steps": x_steps, "lane_code": lane_code, "keep_w": keep_w}
 
 
 def row_subset_fixed(padding_mask: torch.Tensor, steps: int, capacity: int, rowptr: Optional[torch.Tensor],
@@ -2331,8 +2345,10 @@ def row_subset_fixed(padding_mask: torch.Tensor, steps: int, capacity: int, rowp
         raise ValueError("rowptr must be int32 with steps * N + 1 entries")
     cnt = list(edge_counts) + [None] * (3 - len(edge_counts))
     cap = [int(c) for c in edge_caps] + [0] * (3 - len(edge_caps))
+    ws = _workspace(_lib.query("hivt_row_subset_workspace_bytes", n, int(steps)), dev)
     _lib.call("hivt_row_subset", _p(pm), pm.stride(0), n, int(steps), capacity, _p(rowptr), _p(cnt[0]), cap[0], _p(cnt[1]),
-              cap[1], _p(cnt[2]), cap[2], _p(rows), _p(new_id), _p(live), _p(count), _p(packed), _p(overflow), _stream(pm))
+              cap[1], _p(cnt[2]), cap[2], _p(rows), _p(new_id), _p(live), _p(count), _p(packed), _p(overflow), _p(ws),
+              ws.numel(), _stream(pm))
     return RowSubset(rows, new_id, live, count[0], capacity, m, packed, overflow.view(()))
 
 
@@ -2523,29 +2539,34 @@ class _HingeR1Multi(torch.autograd.Function):
     def forward(ctx, w, count, lambda_r1, *rows):
         scales = len(rows) // 3
         rows = [t.contiguous() for t in rows]
-        _need_gpu(w, count, *rows)
+        _need_gpu(w, *rows)
         b = rows[0].shape[0]
         for t in rows:
             if t.shape != (b,) or t.dtype != torch.float32:
                 raise ValueError("hinge_r1_multi: every score / gradient-norm vector must be float32 [B]")
         w = w.contiguous()
-        out = torch.empty(1 + 2 * scales, dtype=torch.float32, device=w.device)
+        out = torch.empty(2 + 2 * scales, dtype=torch.float32, device=w.device)
         _lib.call("hivt_hinge_r1_multi_fwd", _ptr_array(rows[0::3]), _ptr_array(rows[1::3]), _ptr_array(rows[2::3]), scales,
                   _p(w), _p(count), b, float(lambda_r1), _p(out), _stream(w))
-        ctx.save_for_backward(w, count, *rows[0::3], *rows[2::3])
+        # (the last element of `out` holds the number of kept rows, given or computed by the kernel)
+        ctx.save_for_backward(w, out, *rows[0::3], *rows[2::3])
         ctx.cfg = (scales, float(lambda_r1))
-        total, logs = out[0], out[1:]
+        total, logs = out[0], out[1:1 + 2 * scales]
         ctx.mark_non_differentiable(logs)  # only the total is an objective
+        ctx.set_materialize_grads(False)
         return total, logs
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_total, _g_logs):
         scales, lambda_r1 = ctx.cfg
-        w, count, *rest = ctx.saved_tensors
+        w, out, *rest = ctx.saved_tensors
         s_real, s_fake = rest[:scales], rest[scales:]
         b = w.shape[0]
+        if g_total is None:
+            return (None,) * (3 + 3 * scales)
         g_total = g_total.contiguous()
+        count = out[1 + 2 * scales:]
         grads = torch.empty(3 * scales, b, dtype=torch.float32, device=w.device)
         g_real = [grads[3 * k] for k in range(scales)]
         g_norm2 = [grads[3 * k + 1] for k in range(scales)]
@@ -2555,12 +2576,13 @@ class _HingeR1Multi(torch.autograd.Function):
         return (None, None, None, *[grads[i] for i in range(3 * scales)])
 
 
-def hinge_r1_multi(terms, w: torch.Tensor, count: torch.Tensor, lambda_r1: float
+def hinge_r1_multi(terms, w: torch.Tensor, count: Optional[torch.Tensor], lambda_r1: float
                    ) -> Tuple[torch.Tensor, torch.Tensor]:
     """``terms``: per critic scale ``(s_real, grad_norm2, s_fake)`` (at most four scales).  Returns ``(total,
     logs)``: the critics' objective -- the sum over the scales, in order, of ``mean_w relu(1 - s_real) + mean_w
     relu(1 + s_fake) + lambda_r1 * r1`` -- and per scale that term and its ``r1 = mean_w grad_norm2``
-    (``mean_w(v) = sum(w * v) / count``; ``logs[2k]``, ``logs[2k + 1]``, no gradient)."""
+    (``mean_w(v) = sum(w * v) / count``; ``logs[2k]``, ``logs[2k + 1]``, no gradient).  ``count`` None: the number of
+    kept rows ``max(sum(w), 1)`` is computed by the same launch."""
     if not 1 <= len(terms) <= 4:
         raise ValueError("hinge_r1_multi: one to four scales")
     flat = [t for term in terms for t in term]
@@ -2575,25 +2597,29 @@ class _GeneratorTotal(torch.autograd.Function):
     def forward(ctx, losses, w, count, lambda_adv, *scores):
         scales = len(scores)
         scores = [t.contiguous() for t in scores]
-        _need_gpu(losses, w, count, *scores)
+        _need_gpu(losses, w, *scores)
         losses, w = losses.contiguous(), w.contiguous()
         b = w.shape[0]
-        out = torch.empty(2 + scales, dtype=torch.float32, device=w.device)
+        out = torch.empty(3 + scales, dtype=torch.float32, device=w.device)
         _lib.call("hivt_generator_total_fwd", _p(losses), _ptr_array(scores), scales, _p(w), _p(count), b,
                   float(lambda_adv), _p(out), _stream(w))
-        ctx.save_for_backward(w, count)
+        ctx.save_for_backward(w, out)
         ctx.cfg = (scales, float(lambda_adv))
-        total, parts = out[0], out[1:]
+        total, parts = out[0], out[1:2 + scales]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return total, parts
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_total, _g_parts):
         scales, lambda_adv = ctx.cfg
-        w, count = ctx.saved_tensors
+        w, out = ctx.saved_tensors
         b = w.shape[0]
+        if g_total is None:
+            return (None,) * (4 + scales)
         g_total = g_total.contiguous()
+        count = out[2 + scales:]
         g_losses = torch.empty(2, dtype=torch.float32, device=w.device)
         g_s = torch.empty(scales, b, dtype=torch.float32, device=w.device)
         _lib.call("hivt_generator_total_bwd", _p(g_total), scales, _p(w), _p(count), b, lambda_adv, _p(g_losses),
@@ -2601,11 +2627,12 @@ class _GeneratorTotal(torch.autograd.Function):
         return (g_losses, None, None, None, *[g_s[k] for k in range(scales)])
 
 
-def generator_total(losses: torch.Tensor, scores, w: torch.Tensor, count: torch.Tensor, lambda_adv: float
+def generator_total(losses: torch.Tensor, scores, w: torch.Tensor, count: Optional[torch.Tensor], lambda_adv: float
                     ) -> Tuple[torch.Tensor, torch.Tensor]:
     """The generator's objective and its parts in one launch: ``(total, parts)`` with ``total = (reg_loss + cls_loss) +
     g_adv`` for ``losses = (reg_loss, cls_loss)``, ``parts[0] = g_adv = lambda_adv * sum_k g_k`` and ``parts[1 + k] =
-    g_k = -mean_w scores_k`` per critic scale (``models/hivt.py:317-324``; the parts carry no gradient)."""
+    g_k = -mean_w scores_k`` per critic scale (``models/hivt.py:317-324``; the parts carry no gradient).  ``count``
+    None: ``max(sum(w), 1)``, computed by the same launch."""
     if not 1 <= len(scores) <= 4:
         raise ValueError("generator_total: one to four scales")
     return _GeneratorTotal.apply(losses, w, count, float(lambda_adv), *scores)

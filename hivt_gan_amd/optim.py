@@ -29,6 +29,11 @@ class FusedAdamW(torch.optim.AdamW):
         self.use_library_kernel = True
         self._library_meta = {}  # id(list of params) -> host arrays of state addresses and sizes
         self.library_steps = 0   # group updates that went through the library's kernel
+        # per group: a device scalar holding the learning rate the library's kernel reads, and the value it holds.
+        # A schedule changes `group["lr"]`; `sync_lr()` carries the change to the device, so a recorded graph of the
+        # update keeps replaying across learning-rate changes (the rate is not a launch argument).
+        self._lr_dev = {}
+        self.last_step_on_library = False  # every group of the last step() went through the library's kernel
 
     # -- cache management -------------------------------------------------------------------------
     def _untie(self) -> None:
@@ -86,12 +91,28 @@ class FusedAdamW(torch.optim.AdamW):
             for p in group["params"]:
                 p.grad = None
 
+    def sync_lr(self) -> None:
+        """Writes every group's current learning rate into its device scalar if it has changed.  Called by ``step``
+        (outside stream capture) and by whoever replays a recorded step before a replay."""
+        for i, group in enumerate(self.param_groups):
+            slot = self._lr_dev.get(i)
+            if slot is not None and slot[1] != group["lr"] and isinstance(group["lr"], float):
+                slot[0].fill_(group["lr"])
+                slot[1] = group["lr"]
+
+    def _lr_scalar(self, index: int, group, device) -> torch.Tensor:
+        slot = self._lr_dev.get(index)
+        if slot is None or slot[0].device != device:
+            slot = self._lr_dev[index] = [torch.full((), group["lr"], dtype=torch.float32, device=device), group["lr"]]
+        return slot[0]
+
     # -- the update ---------------------------------------------------------------------------------
-    def _library_step(self, group, params, grads, exp_avgs, exp_avg_sqs, step, found_inf) -> bool:
-        """The update of one group through ``hivt_adamw_step`` (up to 96 tensors per launch, 4096-element
+    def _library_step(self, group, params, grads, exp_avgs, exp_avg_sqs, step, found_inf, index=0) -> bool:
+        """The update of one group through ``hivt_adamw_update`` (up to 96 tensors per launch, 4096-element
         pieces) instead of the framework's multi-tensor kernel, whose 65 536-element pieces leave a few
-        hundred small tensors with a handful of busy workgroups per launch.  False: not applicable here
-        (the caller then runs the framework's kernel)."""
+        hundred small tensors with a handful of busy workgroups per launch.  ``step`` holds the number of updates
+        done so far; the call uses ``step + 1`` and advances the counter unless ``found_inf`` is set.  False: not
+        applicable here (the caller then runs the framework's kernel)."""
         if not self.use_library_kernel or not isinstance(group["lr"], float) or step.dtype != torch.float32:
             return False
         for g in grads:
@@ -112,15 +133,38 @@ class FusedAdamW(torch.optim.AdamW):
         _, array, m_ptrs, v_ptrs, numels = meta
         beta1, beta2 = group["betas"]
         # parameter addresses are read every time: a parameter's storage may have been replaced since
-        _lib.call("hivt_adamw_step", array(*map(_DATA_PTR, params)), array(*map(_DATA_PTR, grads)), m_ptrs, v_ptrs,
+        lr_dev = self._lr_scalar(index, group, params[0].device)
+        _lib.call("hivt_adamw_update", array(*map(_DATA_PTR, params)), array(*map(_DATA_PTR, grads)), m_ptrs, v_ptrs,
                   numels, count, step.data_ptr(), found_inf.data_ptr() if found_inf is not None else None,
-                  group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                  lr_dev.data_ptr(), group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
                   torch.cuda.current_stream(params[0].device).cuda_stream)
         self.library_steps += 1
         return True
 
+    def _init_missing_state(self) -> bool:
+        """State for the parameters that hold a gradient and have none yet, in the stock layout (a 0-d float32 step
+        counter on the device, two zero moments), so that the first update already takes the cached path.  False if
+        a group is configured in a way the cached path does not serve."""
+        for group in self.param_groups:
+            if group["amsgrad"] or group["maximize"] or group.get("capturable") or group.get("differentiable"):
+                return False
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse or not p.is_cuda:
+                    return False
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
+        if closure is None and self._lists is None and not torch.cuda.is_current_stream_capturing() \
+                and self._init_missing_state():
+            self._cache()
         lists = self._lists
         if closure is None and lists is not None and len(lists) == len(self.param_groups):
             grads_per_group = []
@@ -143,21 +187,27 @@ class FusedAdamW(torch.optim.AdamW):
             if grads_per_group is not None:
                 found_inf = getattr(self, "found_inf", None)
                 grad_scale = getattr(self, "grad_scale", None)
-                for group, (params, _, exp_avgs, exp_avg_sqs, steps, shared), grads in zip(self.param_groups, lists,
-                                                                                         grads_per_group):
+                if not torch.cuda.is_current_stream_capturing():
+                    self.sync_lr()
+                self.last_step_on_library = True
+                for index, (group, (params, _, exp_avgs, exp_avg_sqs, steps, shared), grads) in enumerate(
+                        zip(self.param_groups, lists, grads_per_group)):
                     if not params:
                         continue
                     beta1, beta2 = group["betas"]
+                    # the library's kernel counts the step itself (one launch less on either side of the update)
+                    if shared is not None and grad_scale is None and self._library_step(
+                            group, params, grads, exp_avgs, exp_avg_sqs, shared, found_inf, index):
+                        continue
+                    self.last_step_on_library = False
                     if shared is not None:
                         shared.add_(1)
                     else:
                         torch._foreach_add_(steps, 1)
-                    if not (shared is not None and grad_scale is None and self._library_step(
-                            group, params, grads, exp_avgs, exp_avg_sqs, shared, found_inf)):
-                        torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
-                                            lr=group["lr"], beta1=beta1, beta2=beta2,
-                                            weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
-                                            grad_scale=grad_scale, found_inf=found_inf)
+                    torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
+                                        lr=group["lr"], beta1=beta1, beta2=beta2,
+                                        weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
+                                        grad_scale=grad_scale, found_inf=found_inf)
                     if found_inf is not None:  # a skipped update does not count as a step
                         if shared is not None:
                             shared.sub_(found_inf.to(shared.dtype).view(()))
@@ -165,6 +215,7 @@ class FusedAdamW(torch.optim.AdamW):
                             torch._foreach_sub_(steps, [found_inf] * len(steps))
                 return None
         self._untie()
+        self.last_step_on_library = False
         out = super().step(closure)
         self._cache()
         return out

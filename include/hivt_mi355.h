@@ -137,15 +137,15 @@ int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_t* count, i
  *   un-rotated rows in the same order, which the edge gather looks its sources up in),
  *   lane_code[l] = (is_intersections[l] * 3 + turn_directions[l]) * 2 + traffic_controls[l] (one row of the
  *   12-row table that sums the three categorical embeddings, models/local_encoder.py:332-334,361-363),
- *   keep_w[n] = 1 if agent n has a valid future step (padding_mask[n, T .. T+Hf) not all set), else 0, and
- *   keep_count[0] = max(sum keep_w, 1) (the masked means of models/hivt.py:227-231 without boolean indexing).
+ *   keep_w[n] = 1 if agent n has a valid future step (padding_mask[n, T .. T+Hf) not all set), else 0 (the
+ *   weights of the masked means that stand in for the boolean indexing of models/hivt.py:227-231).
  * x float [N, *, 2] with element strides; padding_mask uint8 [N, pm_stride >= T + Hf]; lane attributes uint8 [L]. */
 int hivt_batch_prepare(const float* rotate_angles, const float* y, const float* x, int64_t x_stride_n,
                        int64_t x_stride_t, const uint8_t* padding_mask, int64_t pm_stride,
                        const uint8_t* is_intersections, const uint8_t* turn_directions,
                        const uint8_t* traffic_controls, int32_t N, int32_t T, int32_t Hf, int32_t L,
                        float* rotate_mat, float* y_rot, float* x_rot, float* x_steps, int32_t* lane_code,
-                       float* keep_w, float* keep_count, hivt_stream_t stream);
+                       float* keep_w, hivt_stream_t stream);
 
 /* The (step, agent) nodes t*N + n with padding_mask[n][t] == 0, packed in ascending order into `capacity` rows:
  * the agent-agent stage's result at a padded node is overwritten by the padding token before anything reads it
@@ -158,10 +158,12 @@ int hivt_batch_prepare(const float* rotate_angles, const float* y, const float* 
  *                         edges) re-indexed to packed rows; both NULL to skip
  *   overflow[0]           1 if the live count exceeds capacity or any *edge_countK exceeds edge_capK (K = 0..2,
  *                         NULL counters are skipped): the flag a fixed-capacity step discards its batch by. */
+size_t hivt_row_subset_workspace_bytes(int32_t N, int32_t T);
 int hivt_row_subset(const uint8_t* padding_mask, int64_t pm_stride, int32_t N, int32_t T, int32_t capacity,
                     const int32_t* rowptr, const int32_t* edge_count0, int64_t edge_cap0, const int32_t* edge_count1,
                     int64_t edge_cap1, const int32_t* edge_count2, int64_t edge_cap2, int32_t* rows, int32_t* new_id,
-                    uint8_t* live, int32_t* count, int32_t* packed_rowptr, uint8_t* overflow, hivt_stream_t stream);
+                    uint8_t* live, int32_t* count, int32_t* packed_rowptr, uint8_t* overflow, void* workspace,
+                    size_t workspace_bytes, hivt_stream_t stream);
 
 /* Per packed row r (node m = rows[r], step t = m / N, agent n = m % N): xc[r] = x_rot[m] and
  * code[r] = bos_mask[n][t] ? t : -1 -- the inputs of center_embed and of the begin-of-sequence substitution
@@ -662,9 +664,11 @@ int hivt_hinge_r1_bwd(const float* g_loss, const float* s_real, const float* s_f
                       hivt_stream_t stream);
 
 /* The critic loss of ALL scales in one launch (models/hivt.py:305-310: the per-scale terms above, summed in scale
- * order): out[0] = sum_k out[1 + 2k], out[1 + 2k] = loss of scale k, out[2 + 2k] = its R1 penalty; s_real /
- * grad_norm2 / s_fake are HOST arrays of `scales` (1..4) device pointers to B rows each.  The gradient of out[0]
- * goes to g_real[k], g_norm2[k], g_fake[k] (HOST arrays of device pointers). */
+ * order): out[0] = sum_k out[1 + 2k], out[1 + 2k] = loss of scale k, out[2 + 2k] = its R1 penalty, out[1 + 2 scales] =
+ * the number of kept rows; s_real / grad_norm2 / s_fake are HOST arrays of `scales` (1..4) device pointers to B
+ * rows each.  count == NULL in the forward call: the number of kept rows is max(sum_i w_i, 1), computed here (the
+ * backward call takes it from out).  The gradient of out[0] goes to g_real[k], g_norm2[k], g_fake[k] (HOST arrays of
+ * device pointers). */
 int hivt_hinge_r1_multi_fwd(const float* const* s_real, const float* const* grad_norm2, const float* const* s_fake,
                             int32_t scales, const float* w, const float* count, int64_t B, float lambda_r1, float* out,
                             hivt_stream_t stream);
@@ -674,7 +678,8 @@ int hivt_hinge_r1_multi_bwd(const float* g_loss, const float* const* s_real, con
 
 /* The generator's objective in one launch (models/hivt.py:317-324, losses/adv_losses.py:91-98):
  *   out[2 + k] = -sum_i w_i s_fake[k][i] / count,  out[1] = lambda_adv * sum_k out[2 + k] (scale order),
- *   out[0] = (losses[0] + losses[1]) + out[1]   with losses = (regression, classification) loss.
+ *   out[0] = (losses[0] + losses[1]) + out[1]   with losses = (regression, classification) loss,
+ *   out[2 + scales] = count (count == NULL in the forward call: max(sum_i w_i, 1), computed here).
  * Gradient of out[0]: g_losses[0] = g_losses[1] = g_out, g_s[k][i] = -lambda_adv * g_out * w_i / count. */
 int hivt_generator_total_fwd(const float* losses, const float* const* s_fake, int32_t scales, const float* w,
                              const float* count, int64_t B, float lambda_adv, float* out, hivt_stream_t stream);

@@ -43,9 +43,9 @@ def test_replayed_steps_equal_eager_steps():
     order = [0, 1, 2, 1]
     ref_model = make(0.0)
     padded, spec = batches_and_spec(ref_model)
-    # eager reference: the recording's three warm-up steps and its captured step run on padded[0] eagerly too
-    # (capture executes nothing), then the replays
-    eager_run(ref_model, spec, padded, [0, 0, 0] + order)
+    # eager reference: the same steps and nothing else -- the recording's warm-up steps leave no trace in the
+    # parameters, the optimizer state or the critics' power-iteration vectors, and the capture executes nothing
+    eager_run(ref_model, spec, padded, order)
     model = make(0.0)
     trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
     step = GraphedStep(trainer, spec, padded[0], warmup=3)
@@ -154,9 +154,9 @@ def test_two_recordings_of_one_trainer_with_their_own_shapes():
     ref_model = make(0.0)
     spec_all = hv.GanTrainer.calibrate(ref_model, [small, large])
     padded_all = [hv.pad_batch(small, spec_all), hv.pad_batch(large, spec_all)]
-    # both recordings run three warm-up steps and execute nothing while capturing
+    # (the recordings' warm-up steps leave the training state as they found it, and capturing executes nothing)
     order = [0, 1, 0, 0, 1]
-    eager_run(ref_model, spec_all, padded_all, [0, 0, 0, 1, 1, 1] + order)
+    eager_run(ref_model, spec_all, padded_all, order)
     model = make(0.0)
     trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec_all.edge_capacity)
     specs = [hv.GanTrainer.calibrate(model, [b], slack=1.0, node_slack=1.0) for b in (small, large)]
@@ -179,3 +179,63 @@ def test_two_recordings_of_one_trainer_with_their_own_shapes():
             outs.append(m(probe.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), float((a - b).abs().max())
+
+
+def test_recording_leaves_the_training_state_untouched():
+    """``GraphedStep`` warms up with real steps on whatever its static inputs hold; none of that may survive: the
+    parameters, the optimizer state, the critics' power-iteration vectors and the overflow counter are bit-identical
+    before and after a recording, also when a trained state is recorded again (the reference makes exactly one
+    update per batch, ``models/hivt.py:287-342``)."""
+    model = make(0.1)
+    padded, spec = batches_and_spec(model, count=2)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    step = GraphedStep(trainer, spec, padded[0], warmup=3)
+    torch.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), f"{k} changed while recording"
+    for opt in (trainer.opt_g, trainer.opt_d):
+        for st in opt.state.values():
+            assert float(st["step"]) == 0.0 and float(st["exp_avg"].abs().max()) == 0.0 \
+                and float(st["exp_avg_sq"].abs().max()) == 0.0
+    assert trainer.overflowed_steps() == 0
+    step.run(padded[1])
+    step.run(padded[0])
+    torch.cuda.synchronize()
+    trained = {k: v.clone() for k, v in model.state_dict().items()}
+    moments = [{k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for st in trainer.opt_g.state.values()]
+    step.record()  # e.g. a second shape bucket made later, or a schedule that forces a new recording
+    torch.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, trained[k]), f"{k} changed while recording again"
+    for st, ref in zip(trainer.opt_g.state.values(), moments):
+        for k, v in ref.items():
+            assert torch.equal(st[k], v), k
+
+
+def test_learning_rate_change_needs_no_new_recording():
+    """The recorded update reads its learning rate from a device scalar: after ``end_epoch`` the same recording keeps
+    replaying and applies the new rate (equal to eager steps through the same schedule)."""
+    order = [0, 1, 0, 1]
+    ref_model = make(0.0)
+    padded, spec = batches_and_spec(ref_model, count=2)
+    ref = hv.GanTrainer(ref_model, distributed=False, edge_capacity=spec.edge_capacity)
+    for n, i in enumerate(order):
+        ref.step(padded[i].clone())
+        if n == 1:
+            for _ in range(20):
+                ref.end_epoch()
+    model = make(0.0)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    step = GraphedStep(trainer, spec, padded[0])
+    recordings = id(step.segments[0][1])
+    for n, i in enumerate(order):
+        step.run(padded[i])
+        if n == 1:
+            for _ in range(20):
+                trainer.end_epoch()
+    torch.cuda.synchronize()
+    assert id(step.segments[0][1]) == recordings, "the step was recorded again"
+    assert trainer.opt_g.param_groups[0]["lr"] != 5e-4
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
+        assert torch.equal(a, b), f"{k} differs after the learning-rate change"
