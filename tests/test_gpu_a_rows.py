@@ -190,7 +190,7 @@ def test_fused_objectives_equal_the_per_scale_launches():
     for k in range(3):
         assert float((logs[2 * k] - ref_terms[k][0]).abs()) <= 1e-6 * float(ref_terms[k][0].abs())
         assert float((logs[2 * k + 1] - ref_terms[k][1]).abs()) <= 1e-6 * float(ref_terms[k][1].abs())
-    got = torch.autograd.grad(total, rows)
+    got = torch.autograd.grad(total, rows, retain_graph=True)  # (the abs nodes feed both graphs)
     want = torch.autograd.grad(ref_total, rows)
     for a, r in zip(got, want):
         assert float((a - r).abs().max()) <= 1e-6 * max(float(r.abs().max()), 1e-12)
