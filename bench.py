@@ -278,6 +278,9 @@ def main():
                          "workload's precision, results within 2e-2) or fp32 throughout (within 1e-5)")
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the extra timing of the step with the other --matmul precision")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the eager steps that price the edge-attention kernels after the timed region (roofline "
+                         "null; for kernel traces whose last steps should be the timed replays)")
     ap.add_argument("--no-tune", action="store_true", help="keep the default launch schedule (no timing of alternatives)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the recorded step (single-GPU runs record the "
@@ -436,7 +439,7 @@ def main():
     elapsed = timed(args.warmup, args.steps)
     ops.SEG_ATTN_TIMING = None
     logs = {k: v.clone() for k, v in timed.logs.items()}
-    if graphed is not None:
+    if graphed is not None and not args.no_kernel_timing:
         # a replayed graph cannot carry the per-kernel time stamps: the edge-attention kernels are priced on
         # the same number of eagerly launched steps of the same trainer right after the timed region
         ops.SEG_ATTN_TIMING = records

@@ -17,3 +17,8 @@ def golden():
     import numpy as np
     path = os.path.join(ROOT, "tests", "golden", "reference_losses.npz")
     return dict(np.load(path))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import _parity
+    _parity.write(ROOT)

@@ -2,9 +2,13 @@
 
 Bars: bit-exact for edge sets, CSR order and indices; fp32 results within 1e-5 relative
 (rtol 1e-5 plus a small absolute floor for values near zero)."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+import _parity
 
 import hivt_gan_amd as hv
 from hivt_gan_amd import ops
@@ -33,6 +37,9 @@ def close64(gpu, ref32, ref64, rtol=RTOL, msg=""):
     err_gpu = float((g - r64).abs().max()) if r64.numel() else 0.0
     err_ref = float((ref32.detach().double() - r64).abs().max()) if r64.numel() else 0.0
     bound = max(rtol * scale, 2.0 * err_ref)
+    _parity.record(os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], msg or "tensor", gpu, r64, bound,
+                   "rtol" if err_gpu <= rtol * scale else "2x fp32 reference", max_abs_error=err_gpu, scale=scale,
+                   fp32_reference_error=err_ref)
     assert err_gpu <= bound, f"{msg}: gpu err {err_gpu:.3e} > bound {bound:.3e} (scale {scale:.3e}, fp32 ref err {err_ref:.3e})"
 
 
