@@ -172,6 +172,21 @@ def scores_multi(jobs):
             rounds.append([])
         rounds[k].append(idx)
     weights_of = {}
+    same_members = len(rounds) > 1 and all([id(jobs[i][0]) for i in m] == [id(jobs[i][0]) for i in rounds[0]]
+                                           for m in rounds[1:])
+    layers0 = [m for idx in rounds[0] for m in jobs[idx][0]._spectral_layers()]
+    if same_members and len(layers0) <= 16:
+        # every critic evaluated len(rounds) times: all power iterations and normalisations as one node of the graph
+        per_round = ops.spectral_normalize_rounds([m.weight_orig for m in layers0], [m.weight_u for m in layers0],
+                                                  [m.weight_v for m in layers0], len(rounds),
+                                                  jobs[rounds[0][0]][0].training, _EPS)
+        for members, ws in zip(rounds, per_round):
+            at = 0
+            for idx in members:
+                n = len(jobs[idx][0]._spectral_layers())
+                weights_of[idx] = ws[at:at + n]
+                at += n
+        rounds = []
     for members in rounds:
         layers = [(idx, m) for idx in members for m in jobs[idx][0]._spectral_layers()]
         training = jobs[members[0]][0].training

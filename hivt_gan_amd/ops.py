@@ -1286,6 +1286,85 @@ class _SpectralNormalize(torch.autograd.Function):
         return (None, *grads)
 
 
+class _SpectralNormalizeRounds(torch.autograd.Function):
+    """``rounds`` successive calls of ``_SpectralNormalize`` on the same weights (every round advances ``u`` / ``v`` by
+    one power iteration and normalises with ITS sigma) as one node of the graph: outputs round-major, and the
+    gradient of a weight comes out as the sum over the rounds, added in one multi-tensor launch instead of one
+    accumulation per weight."""
+
+    @staticmethod
+    def forward(ctx, state, *weights):
+        us, vs, training, eps, rounds = state
+        _need_gpu(*weights)
+        layers = len(weights)
+        ws = [w.contiguous() for w in weights]
+        dev = ws[0].device
+        rows = (ctypes.c_int32 * layers)(*[w.shape[0] for w in ws])
+        cols = (ctypes.c_int32 * layers)(*[w.shape[1] for w in ws])
+        sizes = [w.shape[0] for w in ws] + [w.shape[1] for w in ws]
+        per_round = sum(_round4(n) for n in sizes)
+        used = torch.empty(rounds * per_round, dtype=torch.float32, device=dev)
+        sigma = torch.empty(rounds * layers, dtype=torch.float32, device=dev)
+        outs = []
+        for r in range(rounds):
+            wn = [torch.empty_like(w) for w in ws]
+            parts = _aligned_parts(used[r * per_round:(r + 1) * per_round], sizes)
+            _lib.call("hivt_spectral_norm_fwd", layers, _ptr_array(ws), _ptr_array(us), _ptr_array(vs), rows, cols,
+                      1 if training else 0, float(eps), _ptr_array(wn), _ptr_array(parts[:layers]),
+                      _ptr_array(parts[layers:]), _p(sigma[r * layers:]), _stream(ws[0]))
+            outs += wn
+        ctx.save_for_backward(used, sigma, *ws)
+        ctx.sizes, ctx.rounds, ctx.per_round = sizes, rounds, per_round
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *d_wn):
+        used, sigma, *ws = ctx.saved_tensors
+        layers, rounds = len(ws), ctx.rounds
+        grads = [None] * layers
+        for r in range(rounds):
+            d_r = d_wn[r * layers:(r + 1) * layers]
+            keep = [i for i, g in enumerate(d_r) if g is not None]
+            if not keep:
+                continue
+            parts = _aligned_parts(used[r * ctx.per_round:(r + 1) * ctx.per_round], ctx.sizes)
+            u_used, v_used = parts[:layers], parts[layers:]
+            gs = [d_r[i].contiguous() for i in keep]
+            outs = [torch.empty_like(ws[i]) for i in keep]
+            sig = sigma[r * layers:(r + 1) * layers]
+            if len(keep) != layers:
+                sig = sig[keep]
+            rows = (ctypes.c_int32 * len(keep))(*[ws[i].shape[0] for i in keep])
+            cols = (ctypes.c_int32 * len(keep))(*[ws[i].shape[1] for i in keep])
+            _lib.call("hivt_spectral_norm_bwd", len(keep), _ptr_array(gs), _ptr_array([ws[i] for i in keep]),
+                      _ptr_array([u_used[i] for i in keep]), _ptr_array([v_used[i] for i in keep]), _p(sig), rows, cols,
+                      _ptr_array(outs), _stream(gs[0]))
+            have = [i for i in keep if grads[i] is not None]
+            if have:  # one multi-tensor launch for the sums over the rounds
+                torch._foreach_add_([grads[i] for i in have], [o for i, o in zip(keep, outs) if grads[i] is not None])
+            for i, o in zip(keep, outs):
+                if grads[i] is None:
+                    grads[i] = o
+        return (None, *grads)
+
+
+def spectral_normalize_rounds(weights, us, vs, rounds: int, training: bool, eps: float = 1e-12):
+    """``rounds`` calls of ``spectral_normalize`` in a row (what ``rounds`` forward calls of a spectrally normalised
+    layer do in training mode) as one node of the autograd graph; returns one list of normalised copies per round."""
+    if len(weights) > 16 or rounds < 1:
+        raise ValueError("at most 16 layers per call, at least one round")
+    for w, u, v in zip(weights, us, vs):
+        if w.dim() != 2 or u.shape != (w.shape[0],) or v.shape != (w.shape[1],):
+            raise ValueError("weights must be [out, in] with u [out] and v [in]")
+        if w.dtype != torch.float32 or not u.is_contiguous() or not v.is_contiguous():
+            raise TypeError("spectral_normalize needs float32 weights and contiguous u / v")
+    _need_gpu(*us, *vs)
+    outs = _SpectralNormalizeRounds.apply((list(us), list(vs), bool(training), eps, int(rounds)), *weights)
+    n = len(weights)
+    return [list(outs[r * n:(r + 1) * n]) for r in range(rounds)]
+
+
 def spectral_normalize(weights, us, vs, training: bool, eps: float = 1e-12):
     """Spectrally normalised copies of ``weights`` (a list of [out, in] matrices, at most 16).  ``us`` /
     ``vs`` are the persistent power-iteration vectors; in training mode they advance by one iteration
@@ -1472,7 +1551,8 @@ class _CriticsMulti(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, plan, *tensors):
         neg_slope, dropout_p = cfg
-        n_inputs, critics, pass_plan = plan
+        n_inputs, critics, pass_plan = plan[:3]
+        ctx.same_as = plan[3] if len(plan) > 3 else None
         xs = tensors[:n_inputs]
         params, at = [], n_inputs
         for n_lin in critics:
@@ -1630,6 +1710,7 @@ class _CriticsMulti(torch.autograd.Function):
                           _p(out), stream)
                 total = out
             grads.append(total.view(x_shapes[i]))
+        param_at = len(grads)
         for c_idx, (n_lin, _) in enumerate(critic_meta):
             if param_grads[c_idx] is None:
                 grads += [None] * (2 * n_lin)
@@ -1637,6 +1718,19 @@ class _CriticsMulti(torch.autograd.Function):
                 dws, dbs, _, _ = param_grads[c_idx]
                 for dw, db in zip(dws, dbs):
                     grads += [dw, db]
+        if ctx.same_as is not None:
+            into, what = [], []
+            for j, first in enumerate(ctx.same_as):
+                if first == j or grads[param_at + j] is None:
+                    continue
+                if grads[param_at + first] is None:
+                    grads[param_at + first] = grads[param_at + j]
+                else:
+                    into.append(grads[param_at + first])
+                    what.append(grads[param_at + j])
+                grads[param_at + j] = None
+            if into:  # one multi-tensor launch for all shared parameters
+                torch._foreach_add_(into, what)
         return tuple(grads)
 
 
@@ -1661,7 +1755,12 @@ def critic_scores_multi(passes, neg_slope: float, dropout_p: float, training: bo
             critics.append(len(weights))
             tensors += [t for pair in zip(weights, biases) for t in pair]
         plan.append((x_index[id(x)], critic_index[key], bool(with_r1), _fresh_seed() if p > 0.0 else 0))
-    outs = _CriticsMulti.apply((float(neg_slope), p), (len(xs), tuple(critics), tuple(plan)), *xs, *tensors)
+    # a parameter tensor that two critics of the call share (the biases of one critic under two normalisations of
+    # its weights): its gradient comes out once, summed, at its first place
+    first_at, same_as = {}, []
+    for j, t in enumerate(tensors):
+        same_as.append(first_at.setdefault(id(t), j))
+    outs = _CriticsMulti.apply((float(neg_slope), p), (len(xs), tuple(critics), tuple(plan), tuple(same_as)), *xs, *tensors)
     result, at = [], 0
     for _, _, _, with_r1 in passes:
         if with_r1:

@@ -46,3 +46,10 @@ print("families (us/step):", {k: round(v / steps / 1e3, 1) for k, v in sorted(fa
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:limit]:
     name = re.sub(r"\(anonymous namespace\)::|void |hivt::", "", n)[:96]
     print(f"{name:96s} {c / steps:7.1f} {t / steps / 1e3:8.1f}us {t / c / 1e3:7.1f}")
+# every launch of the last step, in launch order, for kernels named on the command line after the numbers:
+# python tools/replay_stats.py <dir> 20 60 ln_bwd linear_fwd
+if len(sys.argv) > 4:
+    last = rows[starts[-2]:starts[-1]]
+    for needle in sys.argv[4:]:
+        print("launches of the last step matching %r (position in the step, microseconds):" % needle)
+        print(" ".join("%d:%.1f" % (i, (e - s) / 1e3) for i, (s, e, n) in enumerate(last) if needle in n))
