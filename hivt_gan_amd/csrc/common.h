@@ -64,6 +64,20 @@ int matmul_bf16_mask();
 void reduce_partials(const float* partial, int rows, int cols, float* out, hipStream_t stream,
                      bool accumulate = false);
 
+// Column sums of partial rows, several outputs per launch: out[c] (c < split) and out1[c - split] (c >= split,
+// out1 may be null) (+)= sum over the terms t and their rows r < rows[t] of term[t][r * pitch + c], c < cols; per
+// term four row slices summed in ascending order and combined in slice order, terms added in term order.
+struct ColumnSums {
+  const float* term[4];
+  int32_t rows[4];   // 0: no such term
+  int64_t pitch;
+  float* out;
+  float* out1;
+  int32_t cols, split;
+  int32_t accumulate;
+};
+int reduce_column_sums_group(const ColumnSums* entries, int count, hipStream_t stream);
+
 // dw[N,K] += dy[M,N]^T x[M,K] (hivt_linear_wgrad without the bias sums, added to what dw holds)
 int linear_wgrad_accumulate(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, int64_t M, int32_t N,
                             int32_t K, float* dw, void* workspace, size_t workspace_bytes, hivt_stream_t stream);

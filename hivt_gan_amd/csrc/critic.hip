@@ -123,9 +123,17 @@ int make_shape(const char* what, int64_t B, int32_t layers, const int32_t* width
 struct Scratch {
   float* dz[kMaxHidden + 1];  // dz[l]: [B, w_l], l = 1..L
   float* e[kMaxHidden + 1];   // e[l]: [B, w_l], l = 0..L
+  float* out_part[2];         // output layer's gradient per 64-row tile, [tiles][out_part_pitch]: score / penalty chain
   void* wgrad_ws;
   size_t wgrad_bytes;
 };
+
+constexpr int kOutTileRows = 64;  // = the rows a workgroup of the layer chain carries
+int64_t out_part_pitch(const Shape& s) { return (int64_t)(s.w[s.L] + 1 + 3) / 4 * 4; }
+int64_t out_part_tiles(const Shape& s) { return ((s.B > 0 ? s.B : 1) + kOutTileRows - 1) / kOutTileRows; }
+size_t out_part_bytes(const Shape& s) {
+  return align_up((size_t)(out_part_tiles(s) * out_part_pitch(s)) * sizeof(float), 256);
+}
 
 size_t act_bytes(const Shape& s, int l) {
   return align_up((size_t)(s.B > 0 ? s.B : 1) * s.w[l] * sizeof(float), 256);
@@ -144,6 +152,7 @@ size_t scratch_bytes(const Shape& s) {
   size_t total = group_bytes(s);
   for (int l = 1; l <= s.L; ++l) total += act_bytes(s, l);
   for (int l = 0; l <= s.L; ++l) total += act_bytes(s, l);
+  total += 2 * out_part_bytes(s);
   return total;
 }
 
@@ -157,6 +166,10 @@ Scratch carve(const Shape& s, void* ws) {
   for (int l = 0; l <= s.L; ++l) {
     k.e[l] = reinterpret_cast<float*>(p);
     p += act_bytes(s, l);
+  }
+  for (int i = 0; i < 2; ++i) {
+    k.out_part[i] = reinterpret_cast<float*>(p);
+    p += out_part_bytes(s);
   }
   k.wgrad_ws = p;
   k.wgrad_bytes = group_bytes(s);
@@ -419,6 +432,8 @@ struct ChainPass {
   float* dz[kChainLayers + 1];            // backward: dz[l] [B, w_l], l = 1..L
   float* e[kChainLayers + 1];             // backward: e[l] [B, w_l], l = 0..L
   float* dx;                              // backward, optional
+  float* out_part[2];                     // backward, optional: this pass's per-tile sums of the output layer's
+  int64_t out_pitch;                      // gradient, [tiles][out_pitch]: [0] g^T h_L | sum g, [1] column sums of e_L | 0
 };
 
 struct ChainArgs {
@@ -506,6 +521,30 @@ __device__ __forceinline__ void chain_gate_init(const float* row, const float* v
   }
 }
 
+// part[c] = sum over the tile's rows r of (row ? row[r] : 1) * m[r][c], c < W; part[W] = sum of row[r] (0 without
+// `row`).  A wave per row, rows in ascending order, the four waves' sums added in wave order.
+__device__ __forceinline__ void chain_column_sums(const float* row, const float* m, int W, int B, int row0, float* part,
+                                                  float* lds) {
+  static_assert(kThreads == 256 && kChainRows == 64, "four waves over 64 rows");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int end = min(B, row0 + kChainRows);
+  for (int cb = 0; cb < W; cb += 64) {
+    const int c = cb + lane;
+    float s = 0.0f;
+    if (c < W)
+      for (int r = row0 + wave; r < end; r += 4) s += (row != nullptr ? row[r] : 1.0f) * m[(int64_t)r * W + c];
+    lds[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < W) part[c] = ((lds[lane] + lds[64 + lane]) + lds[128 + lane]) + lds[192 + lane];
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float s = (row != nullptr && row0 + lane < end) ? row[row0 + lane] : 0.0f;
+    s = wave_sum(s);
+    if (lane == 0) part[W] = s;
+  }
+}
+
 template <int PF, int PD>
 __global__ __launch_bounds__(kThreads) void critic_chain_kernel(const ChainArgs g, int backward) {
   using CF = Core<kChainRows, 128, true, true, true, false, 1, PF>;
@@ -566,7 +605,11 @@ __global__ __launch_bounds__(kThreads) void critic_chain_kernel(const ChainArgs 
   }
 
   // ---- backward ----
+  const int64_t tile = (int)blockIdx.x - g.first_block[pi];
   if (p.g_scores != nullptr) {
+    // the output layer's own gradient, this tile's share: dw_o = g^T h_L, db_o = sum g
+    if (p.out_part[0] != nullptr)
+      chain_column_sums(p.g_scores, p.saved + p.h_off[L], p.w[L], B, row0, p.out_part[0] + tile * p.out_pitch, lds);
     // dz_L = (g w_o) * c_L, then dz_{l-1} = (dz_l W_l) * c_{l-1}
     chain_gate_init(p.g_scores, w_o, p.saved + p.h_off[L], p.w[L], B, row0, keep_scale, g.neg_slope, p.dz[L]);
     chain_sync();
@@ -595,6 +638,9 @@ __global__ __launch_bounds__(kThreads) void critic_chain_kernel(const ChainArgs 
                           p.saved + p.h_off[l], keep_scale, keep_scale * g.neg_slope, p.e[l], lds);
       chain_sync();
     }
+    // the penalty's share of dw_o: the column sums of e_L (no bias term)
+    if (p.out_part[1] != nullptr)
+      chain_column_sums(nullptr, p.e[L], p.w[L], B, row0, p.out_part[1] + tile * p.out_pitch, lds);
   }
 }
 
@@ -1074,6 +1120,11 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
     c.g_scores = b.g_scores; c.g_norm2 = b.g_norm2; c.dx = b.dx;
     for (int l = 1; l <= s.L; ++l) c.dz[l] = d.k.dz[l];
     for (int l = 0; l <= s.L; ++l) c.e[l] = d.k.e[l];
+    if (params) {  // the output layer's gradient leaves the chain as per-tile sums
+      c.out_part[0] = d.scores_chain ? d.k.out_part[0] : nullptr;
+      c.out_part[1] = d.penalty_chain ? d.k.out_part[1] : nullptr;
+      c.out_pitch = out_part_pitch(s);
+    }
     a.first_block[a.count + 1] = a.first_block[a.count] + (int32_t)((s.B + kChainRows - 1) / kChainRows);
     done.push_back(d);
     was_chained[(size_t)i] = 1;
@@ -1137,16 +1188,7 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
       terms += t.count;
       t.count = 0;
     };
-    // output layer: dw_o = g^T h_L, db_o = sum g (a one-column product: not groupable, so later passes add)
-    bool first = true;
-    for (size_t i : set) {
-      const Done& d = done[i];
-      if (!d.scores_chain) continue;
-      t.add(d.b.g_scores, 1, d.b.saved + s.h_off[s.L], s.w[s.L], d.b.B, 1, s.w[s.L], f.b.dw[s.L], f.b.dbias[s.L], !first,
-            false);
-      first = false;
-    }
-    flush_terms();
+    // (output layer: dw_o = g^T h_L + column sums of e_L and db_o = sum g come from the chain's per-tile sums, below)
     for (int l = s.L; l >= 1; --l) {
       bool head = true;
       for (size_t i : set) {
@@ -1172,17 +1214,35 @@ extern "C" int hivt_critics_bwd(const int64_t* passes, int32_t count, float neg_
     const size_t left = workspace_bytes - (size_t)(ws - reinterpret_cast<char*>(workspace));
     HIVT_TRY(hivt_linear_wgrad_group(table.data(), terms, ws, left, stream));
   }
+  // the output layers of all sets in one launch: per set the score chains' tiles, then the penalty chains' tiles,
+  // four terms per entry (a longer set continues in entries that add to what the ones before them wrote, issued
+  // in launches of their own so that they run afterwards)
+  std::vector<std::vector<ColumnSums>> waves;
   for (const auto& set : sets) {
-    bool written = false;
-    for (size_t i : set) written |= done[i].scores_chain;
-    for (size_t i : set) {
-      const Done& d = done[i];
-      if (!d.penalty_chain) continue;
-      // dw_o (+)= column sums of e_L (rows summed in a fixed order)
-      reduce_partials(d.k.e[d.s.L], (int)d.b.B, d.s.w[d.s.L], d.b.dw[d.s.L], st, written);
-      written = true;
+    const Done& f = done[set[0]];
+    const Shape& s = f.s;
+    std::vector<std::pair<const float*, int32_t>> terms_of;
+    for (size_t i : set)
+      if (done[i].scores_chain) terms_of.push_back({done[i].k.out_part[0], (int32_t)out_part_tiles(done[i].s)});
+    for (size_t i : set)
+      if (done[i].penalty_chain) terms_of.push_back({done[i].k.out_part[1], (int32_t)out_part_tiles(done[i].s)});
+    for (size_t first = 0, wave = 0; first < terms_of.size(); first += 4, ++wave) {
+      ColumnSums c{};
+      for (size_t t = 0; t < 4 && first + t < terms_of.size(); ++t) {
+        c.term[t] = terms_of[first + t].first;
+        c.rows[t] = terms_of[first + t].second;
+      }
+      c.pitch = out_part_pitch(s);
+      c.out = f.b.dw[s.L];
+      c.out1 = f.b.dbias[s.L];
+      c.cols = s.w[s.L] + 1;
+      c.split = s.w[s.L];
+      c.accumulate = wave > 0 ? 1 : 0;
+      if (waves.size() <= wave) waves.resize(wave + 1);
+      waves[wave].push_back(c);
     }
   }
+  for (const auto& w : waves) HIVT_TRY(reduce_column_sums_group(w.data(), (int)w.size(), st));
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
 }

@@ -767,6 +767,36 @@ void reduce_partials(const float* partial, int rows, int cols, float* out, hipSt
   launch_reduce_rows(stream, partial, rows, (int64_t)cols, cols, out, 0x7fffffff, nullptr, accumulate ? 1 : 0);
 }
 
+int reduce_column_sums_group(const ColumnSums* entries, int count, hipStream_t stream) {
+  static_assert(kJoinMax == 4, "ColumnSums carries four terms");
+  for (int first = 0; first < count; first += kGroupMax) {
+    ReduceGroup g{};
+    const int n = count - first < kGroupMax ? count - first : kGroupMax;
+    g.count = n;
+    g.first_block[0] = 0;
+    for (int i = 0; i < n; ++i) {
+      const ColumnSums& c = entries[first + i];
+      if (c.cols <= 0 || c.split <= 0 || c.out == nullptr || c.rows[0] <= 0 || c.term[0] == nullptr) {
+        set_error("reduce_column_sums_group: entry %d: bad sizes or null pointers", first + i);
+        return HIVT_ERR_ARG;
+      }
+      ReduceEntry& e = g.e[i];
+      for (int t = 0; t < kJoinMax; ++t) {
+        e.term_base[t] = c.term[t];
+        e.term_chunks[t] = c.term[t] != nullptr ? c.rows[t] : 0;
+      }
+      e.pitch = c.pitch;
+      e.out = c.out; e.out1 = c.out1;
+      e.cols = c.cols; e.split = c.split;
+      e.accumulate = c.accumulate;
+      e.K = c.split; e.ld = c.split;
+      g.first_block[i + 1] = g.first_block[i] + (c.cols + 255) / 256;
+    }
+    hipLaunchKernelGGL(reduce_group_kernel, dim3((unsigned)g.first_block[n]), dim3(256), 0, stream, g);
+  }
+  return HIVT_OK;
+}
+
 }  // namespace hivt
 
 using namespace hivt;
