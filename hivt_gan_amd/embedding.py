@@ -103,12 +103,18 @@ class MultipleInputEmbedding(nn.Module):
             hidden = [ops.fused_linear(inp, br[0].weight, br[0].bias, layer_norm=br[1], relu=True)
                       for br, inp in zip(self.module_list, branch_inputs)]
             h = hidden[0] if len(hidden) == 1 else torch.cat(hidden, dim=-1)
+        a = self.aggr_embed
+        if len(self.module_list) == 2 and h.is_cuda:
+            # (the two layers' own parameters go down: their gradients come back per layer, as leaves of the graph)
+            first, second = self.module_list[0][3], self.module_list[1][3]
+            h = ops.fused_linear(h, first.weight, first.bias, add=extra, layer_norm=a[0], relu=True, add_index=extra_index,
+                                 weight_b=second.weight, bias_b=second.bias)
+            return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
         weight = self.module_list[0][3].weight if len(self.module_list) == 1 else \
             torch.cat([br[3].weight for br in self.module_list], dim=1)
         bias = self.module_list[0][3].bias
         for br in self.module_list[1:]:
             bias = bias + br[3].bias
-        a = self.aggr_embed
         h = ops.fused_linear(h, weight, bias, add=extra, layer_norm=a[0], relu=True, add_index=extra_index)
         return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
 

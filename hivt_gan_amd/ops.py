@@ -812,12 +812,22 @@ def _ln_backward(dy2, z, z_ld, stats, gamma, beta, relu: int, m: int, n: int, ad
 class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index, dropout_p, seed, residual):
+    def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index, dropout_p, seed, residual,
+                weight_b=None, bias_b=None):
         _need_gpu(x, weight)
         lead = x.shape[:-1]
         x2 = _rows2(x)
         m, k = x2.shape
         n = weight.shape[0]
+        # two layers on two column blocks of x whose outputs are summed: one product with the weights side by side
+        # and the biases added up; their gradients go to the two layers' own parameters (backward)
+        ctx.pair = None
+        if weight_b is not None:
+            if (bias is None) != (bias_b is None) or weight_b.shape[0] != n:
+                raise ValueError("the two layers of a pair have the same output width and both or neither a bias")
+            ctx.pair = (int(weight.shape[1]), _all_leaves(weight, bias), _all_leaves(weight_b, bias_b))
+            weight = torch.cat([weight, weight_b], dim=1)
+            bias = bias + bias_b if bias is not None else None
         if weight.shape[1] != k:
             raise ValueError(f"weight {tuple(weight.shape)} does not match input width {k}")
         w2 = _rows2(weight)
@@ -856,7 +866,7 @@ class _FusedLinear(torch.autograd.Function):
                    tuple(residual.shape) if residual is not None else None)
         ctx.res_leaf = residual is not None and residual.is_leaf
         ctx.add_leaf = add is not None and add.is_leaf
-        ctx.param_leaves = _all_leaves(weight, bias)
+        ctx.param_leaves = _all_leaves(weight, bias) if ctx.pair is None else None
         ctx.norm_leaves = _all_leaves(gamma, beta) if ln else None
         return y.view(*lead, n)
 
@@ -897,7 +907,15 @@ class _FusedLinear(torch.autograd.Function):
                 _lib.call("hivt_linear_bwd_data", _p(dz), dz.stride(0), _p(w2), w2.stride(0), m, n, k, None, 0, 1.0, None,
                           0, _p(dx), k, s)
             dx = dx.view(*lead, k)
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        dw_b = db_b = None
+        if ctx.pair is not None:
+            k0, leaves_a, leaves_b = ctx.pair
+            if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+                dw, db = _weight_grad(dz, dz.stride(0), x2, x2.stride(0), m, n, k0, dev, bias=has_bias, leaves=leaves_a)
+            if ctx.needs_input_grad[12] or (has_bias and ctx.needs_input_grad[13]):
+                dw_b, db_b = _weight_grad(dz, dz.stride(0), x2[:, k0:], x2.stride(0), m, n, k - k0, dev, bias=has_bias,
+                                          leaves=leaves_b)
+        elif ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = _weight_grad(dz, dz.stride(0), x2, x2.stride(0), m, n, k, dev, bias=has_bias,
                                   leaves=ctx.param_leaves)
         dadd = None
@@ -912,7 +930,7 @@ class _FusedLinear(torch.autograd.Function):
                           ws.numel(), s)
         dres = _pass_through_grad(dy, res_shape, ctx.res_leaf) \
             if (res_shape is not None and ctx.needs_input_grad[11]) else None
-        return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres
+        return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres, dw_b, db_b
 
 
 # --------------------------------------------------------------------------------------------
@@ -1154,11 +1172,14 @@ def layer_norm_residual(x: torch.Tensor, norm: torch.nn.LayerNorm) -> Tuple[torc
 def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                  add: Optional[torch.Tensor] = None, layer_norm: Optional[torch.nn.LayerNorm] = None,
                  relu: bool = False, add_index: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
-                 training: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 training: bool = False, residual: Optional[torch.Tensor] = None,
+                 weight_b: Optional[torch.Tensor] = None, bias_b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[residual +] [dropout]([relu]([layer_norm](x @ weight.T + bias [+ add])))`` in one launch (exact
     fp32 on the matrix cores).  With ``add_index`` (int32, one entry per row) ``add`` is a small table
     [codes <= 16, N] and row m adds ``add[add_index[m]]``.  Dropout (active when ``training``) and the
-    residual are part of the plain epilogues only (no ``layer_norm``).
+    residual are part of the plain epilogues only (no ``layer_norm``).  With ``weight_b`` / ``bias_b`` the product is
+    ``x[:, :k0] @ weight.T + x[:, k0:] @ weight_b.T + bias + bias_b`` (two layers whose outputs are summed, as one
+    product over the weights side by side).
 
     CPU tensors are refused; a LayerNorm epilogue wider than 128 columns raises ``UnsupportedShapeError``."""
     _need_gpu(x, weight)
@@ -1170,7 +1191,7 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0
     return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps, add_index, p,
-                              _fresh_seed() if p > 0.0 else 0, residual)
+                              _fresh_seed() if p > 0.0 else 0, residual, weight_b, bias_b)
 
 
 # --------------------------------------------------------------------------------------------
