@@ -487,7 +487,12 @@ int hivt_reduce_rows_group(const int64_t* items, int32_t count, hivt_stream_t st
  * for the fused projection qkv float [S,N,3D] (q | k | v, each D wide, head h at columns h*D/H..),
  * S <= 32.  Replaces the attention inside nn.MultiheadAttention(x, x, x, attn_mask=causal) of
  * TemporalEncoderLayer._sa_block (models/local_encoder.py:271-276, mask :237-241) including its
- * dropout on the attention weights.  Saves lse float [N,H,S] for the backward. */
+ * dropout on the attention weights.  Saves lse float [N,H,S] for the backward.
+ * Arithmetic: fp32 throughout, except for D = 128, H = 8 while hivt_set_matmul_bf16 has HIVT_BF16_FWD_SPLIT set --
+ * then the two products of a head run on the matrix cores with every operand entering as a (hi, lo) pair of
+ * bfloat16 numbers (sixteen mantissa bits; outputs within 1e-4 of fp64), and in the backward the rebuilt scores
+ * and dP likewise while dQ, dK, dV take operands rounded to bfloat16, as the dense gradient products of that mode
+ * do (gradients within 5e-3 normwise).  The dropout decisions are the same on both routes. */
 int hivt_temporal_attn_fwd(const float* qkv, int32_t S, int32_t N, int32_t D, int32_t H, float dropout_p,
                            uint64_t seed, const uint64_t* seed_ptr, float* out, float* lse, hivt_stream_t stream);
 

@@ -529,6 +529,54 @@ def test_temporal_attention_vs_oracle(S, N, D, H):
     close64(tg.grad, g32, g64, msg="d_qkv")
 
 
+@pytest.mark.parametrize("S,N", [(21, 37), (32, 5), (1, 4), (7, 300)])
+def test_temporal_attention_on_the_matrix_cores_vs_oracle(S, N):
+    """D = 128 with 16-wide heads while the dense products run on bfloat16 operands: the attention core takes the
+    matrix-core kernels.  Forward products and the scores / dP of the backward take split operands (sixteen mantissa
+    bits): outputs within 1e-4 of the float64 oracle.  The three gradient products take operands rounded to bfloat16
+    like the dense layers' gradient products of this mode: gradients within 5e-3 normwise and 2e-2 of the tensor's
+    scale elementwise (the mode's bar for gradients).  With dropout the kernels draw the very masks of the scalar
+    kernels, so both routes agree to the same bars under the same seed."""
+    D, H = 128, 8
+    gen = torch.Generator().manual_seed(S * N + 1)
+    qkv = torch.randn(S, N, 3 * D, generator=gen)
+    w = torch.randn(S, N, D, generator=gen)
+    t = qkv.double().clone().requires_grad_(True)
+    d = D // H
+    q, k, v = (t[..., i * D:(i + 1) * D].reshape(S, N * H, d).transpose(0, 1) for i in range(3))
+    mask = torch.triu(torch.full((S, S), float("-inf"), dtype=torch.float64), diagonal=1)
+    prob = torch.softmax(torch.baddbmm(mask, q / d ** 0.5, k.transpose(-2, -1)), dim=-1)
+    o64 = torch.bmm(prob, v).transpose(0, 1).reshape(S, N, D)
+    (o64 * w.double()).sum().backward()
+
+    def run(mode, p=0.0):
+        previous = ops.set_matmul_precision(mode)
+        try:
+            tg = qkv.to(DEV).requires_grad_(True)
+            torch.manual_seed(5)
+            with ops.seed_scope():  # (draws its base from the host generator on entry)
+                o = ops.temporal_attention(tg, H, dropout_p=p, training=p > 0.0)
+                (o * w.to(DEV)).sum().backward()
+            return o.detach(), tg.grad
+        finally:
+            ops.set_matmul_precision(previous)
+
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    o, g = run("bf16")
+    for name, got, want, normwise, elementwise in (("out", o, o64, 1e-4, 1e-4), ("d_qkv", g, t.grad, 5e-3, 2e-2)):
+        e = _parity.record(test, name, got, want, normwise)
+        assert e <= normwise, (name, e)
+        scale = float(want.detach().abs().max())
+        assert float((got.cpu().double() - want.detach()).abs().max()) <= elementwise * scale, name
+    if S > 1:
+        o_scalar, g_scalar = run("fp32", 0.3)
+        o_drop, g_drop = run("bf16", 0.3)
+        assert float((o_drop - o_scalar).abs().max()) <= 1e-4 * float(o_scalar.abs().max())
+        assert float((g_drop - g_scalar).abs().max()) <= 2e-2 * float(g_scalar.abs().max())
+        assert float((g_drop - g_scalar).norm()) <= 5e-3 * float(g_scalar.norm())
+        assert float((o_drop - o).abs().max()) > 1e-2  # (the masks did something)
+
+
 def test_temporal_attention_dropout_mask_consistency():
     S, N, D, H, p = 21, 200, 128, 8, 0.2
     qkv = torch.zeros(S, N, 3 * D, device=DEV)
