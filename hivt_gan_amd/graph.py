@@ -285,6 +285,13 @@ class GraphedStep:
     def load(self, batch: TemporalData) -> None:
         """Copies a batch padded to the same ``BatchSpec`` into the static inputs: one copy for a batch that
         ``pack_inputs`` laid out like them, one copy per tensor otherwise."""
+        # the route of the edge construction was fixed when the step was recorded: a recording made on batches whose
+        # candidate lists are all ordered pairs builds those pairs itself and never reads `edge_index`, so a batch
+        # with another candidate list would silently get the wrong edge set
+        if bool(batch.get("all_pairs", False)) != bool(self.static.get("all_pairs", False)):
+            raise ValueError("this step was recorded for batches with all_pairs = %s; the batch has all_pairs = %s "
+                             "(record a step of its own for such batches, or launch them eagerly)"
+                             % (bool(self.static.get("all_pairs", False)), bool(batch.get("all_pairs", False))))
         if batch.get("_arena_layout") is not None and batch["_arena_layout"] == self.static["_arena_layout"]:
             self.static["_arena"].copy_(batch["_arena"], non_blocking=True)
             return

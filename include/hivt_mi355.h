@@ -119,7 +119,10 @@ int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t 
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same results
  * as hivt_csr_build.  Sizes beyond the maxima are rejected with HIVT_ERR_ARG.  The device must be
  * current and own `stream`.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two streams, two threads) race; calls on one stream are ordered and safe. */
+ * (two streams, two threads) race; calls on one stream are ordered and safe.  The first call on a device looks
+ * the array's address up (hipGetSymbolAddress, which may load the code object and cannot be captured): make one
+ * call per device outside any stream capture first; every later call is kernel launches only and records into a
+ * HIP graph like them. */
 #define HIVT_CSR_STATIC_MAX_EDGES (1 << 20)
 #define HIVT_CSR_STATIC_MAX_ROWS (1 << 20)
 int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,

@@ -239,3 +239,18 @@ def test_learning_rate_change_needs_no_new_recording():
     assert trainer.opt_g.param_groups[0]["lr"] != 5e-4
     for (k, a), (_, b) in zip(model.state_dict().items(), ref_model.state_dict().items()):
         assert torch.equal(a, b), f"{k} differs after the learning-rate change"
+
+
+def test_a_batch_with_another_candidate_list_is_refused():
+    """The recording built its agent-agent edges from all ordered pairs; a batch that says its candidate list is
+    something else must not be replayed through it."""
+    model = make(0.0)
+    padded, spec = batches_and_spec(model, count=1)
+    trainer = hv.GanTrainer(model, distributed=False, edge_capacity=spec.edge_capacity)
+    step = GraphedStep(trainer, spec, padded[0])
+    assert bool(step.static.get("all_pairs", False))
+    other = padded[0].clone()
+    other["all_pairs"] = False
+    with pytest.raises(ValueError, match="all_pairs"):
+        step.run(other)
+    step.run(padded[0])

@@ -73,3 +73,35 @@ def test_static_scratch_rejects_oversize_inputs():
     assert rc == -1 and b"exceed the static scratch" in lib.hivt_last_error()
     rc = lib.hivt_csr_build_static(key.data_ptr(), 8, None, (1 << 20) + 1, out.data_ptr(), out.data_ptr(), stream)
     assert rc == -1
+
+
+def test_static_scratch_csr_build_inside_a_recorded_graph():
+    """What the entry point exists for: after ONE eager call on the device (which looks the scratch array's address
+    up, not a capturable operation) the call records into a HIP graph like any kernel launch; replays on new keys
+    in the same buffers give what ``hivt_csr_build`` gives."""
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    e, rows = 30_000, 900
+    key = torch.randint(0, rows, (e,), generator=g, dtype=torch.int32).to(dev)
+    rowptr = torch.full((rows + 1,), -7, dtype=torch.int32, device=dev)
+    perm = torch.full((e,), -7, dtype=torch.int32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.hivt_csr_build_static(key.data_ptr(), e, None, rows, rowptr.data_ptr(), perm.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        s = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.hivt_csr_build_static(key.data_ptr(), e, None, rows, rowptr.data_ptr(), perm.data_ptr(), s)
+    assert rc == 0, lib.hivt_last_error().decode()
+    for seed in (6, 7):
+        fresh = torch.randint(0, rows, (e,), generator=torch.Generator().manual_seed(seed), dtype=torch.int32).to(dev)
+        key.copy_(fresh)
+        rowptr.fill_(-7)
+        perm.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.sort(fresh.long(), stable=True).indices.to(torch.int32)
+        assert torch.equal(perm, ref)
+        deg = torch.bincount(fresh.long(), minlength=rows)
+        assert torch.equal(rowptr.long(), torch.cat([deg.new_zeros(1), deg.cumsum(0)]))
