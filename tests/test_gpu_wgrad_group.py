@@ -154,3 +154,37 @@ def test_grouped_row_sums_equal_the_single_layer_norm_backward_calls():
     with pytest.raises(_lib.HivtLibraryError):
         _lib.call("hivt_reduce_rows_group", (ctypes.c_int64 * 8)(p.data_ptr(), 4, 2, 40, acc.data_ptr(), 50, 0, 0), 1,
                   stream)  # a pitch below the column count
+
+
+def test_deferred_products_keep_to_their_contract():
+    """Inside ``deferred_weight_grads()`` a weight gradient is queued only while its parameters have no gradient yet
+    (a populated ``.grad`` -- gradient accumulation -- takes the product on the spot and accumulates correctly), and a
+    parameter that two nodes of one graph share makes the pass raise instead of summing unfilled buffers."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(128, 128).to(DEV)
+    x = torch.randn(300, 128, device=DEV)
+    w_ref = torch.randn(300, 128, device=DEV)
+    (torch.nn.functional.linear(x, lin.weight, lin.bias) * w_ref).sum().backward()
+    want_w, want_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+    # (1) deferred, gradients start empty: filled at the end of the pass
+    lin.weight.grad = lin.bias.grad = None
+    with ops.deferred_weight_grads():
+        (ops.fused_linear(x, lin.weight, lin.bias) * w_ref).sum().backward()
+    assert float((lin.weight.grad - want_w).abs().max()) <= 1e-4 * float(want_w.abs().max())
+    assert float((lin.bias.grad - want_b).abs().max()) <= 1e-4 * float(want_b.abs().max())
+    # (2) gradients already populated: the second pass adds to them
+    with ops.deferred_weight_grads():
+        (ops.fused_linear(x, lin.weight, lin.bias) * w_ref).sum().backward()
+    assert float((lin.weight.grad - 2 * want_w).abs().max()) <= 2e-4 * float(want_w.abs().max())
+    assert float((lin.bias.grad - 2 * want_b).abs().max()) <= 2e-4 * float(want_b.abs().max())
+    # (3) one parameter, two nodes of one graph: refused
+    lin.weight.grad = lin.bias.grad = None
+    x2 = torch.randn(300, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="not adopted"):
+        with ops.deferred_weight_grads():
+            (ops.fused_linear(x, lin.weight, lin.bias) + ops.fused_linear(x2, lin.weight, lin.bias)).sum().backward()
+    # ... and fine outside the scope
+    lin.weight.grad = lin.bias.grad = None
+    (ops.fused_linear(x, lin.weight, lin.bias) + ops.fused_linear(x2, lin.weight, lin.bias)).sum().backward()
+    ref = (x.sum(0) + x2.sum(0)).unsqueeze(0).expand(128, 128)
+    assert float((lin.weight.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
