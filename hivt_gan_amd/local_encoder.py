@@ -454,7 +454,6 @@ class TemporalEncoderLayer(nn.Module):
         mha = self.self_attn
         S, N, D = src.shape
         H, hd = mha.num_heads, D // mha.num_heads
-        xn = ops.layer_norm(src, self.norm1)
         w, b = mha.in_proj_weight, mha.in_proj_bias
         gpu = src.is_cuda
 
@@ -467,9 +466,19 @@ class TemporalEncoderLayer(nn.Module):
             y = F.dropout(y, kw.get("dropout_p", 0.0), kw.get("training", False))
             return y if kw.get("residual") is None else kw["residual"] + y
 
-        if gpu and N > 0 and ops.seg_attn_supported(D, H):
+        if gpu and N > 0 and ops.seg_attn_supported(D, H) and D <= 128 and w.is_contiguous():
             # one query per agent over its own S steps: the segment-attention kernel on the [S, N, 2D] keys and
-            # values as they lie (the j-th "edge" of agent n is row j * N + n)
+            # values as they lie (the j-th "edge" of agent n is row j * N + n).  The last-row slices (query input,
+            # residual) and the two halves of the fused projection stay inside two nodes of the graph.
+            xn, last = ops.layer_norm_last(src, self.norm1, N)
+            q, kv = ops.last_row_qkv(xn, w, b, N)
+            o = ops.seg_attn(q, kv, _step_rowptr(N, S, src.device), H, mha.dropout, self.training, interleaved=True,
+                             tag=type(self).__name__)
+            x = lin(o, mha.out_proj.weight, mha.out_proj.bias, dropout_p=self.dropout1.p, training=self.training,
+                    residual=last)
+            return self._ff_residual(x)
+        xn = ops.layer_norm(src, self.norm1)
+        if gpu and N > 0 and ops.seg_attn_supported(D, H):
             q = lin(xn[-1], w[:D], b[:D])
             kv = lin(xn, w[D:], b[D:]).view(S * N, 2 * D)
             o = ops.seg_attn(q, kv, _step_rowptr(N, S, src.device), H, mha.dropout, self.training, interleaved=True,

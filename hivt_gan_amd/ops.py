@@ -1115,7 +1115,7 @@ class _LayerNorm(torch.autograd.Function):
     kernel instead of in a separate pass over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, last=0):
         _need_gpu(x, gamma, beta)
         lead = x.shape[:-1]
         x2 = _rows2(x)
@@ -1127,8 +1127,13 @@ class _LayerNorm(torch.autograd.Function):
                   _stream(x))
         ctx.save_for_backward(x2, stats, gamma_c, beta_c)
         ctx.lead = tuple(lead)
+        ctx.last = int(last)
         ctx.norm_leaves = _all_leaves(gamma, beta)
         ctx.set_materialize_grads(False)
+        if last:  # only the last `last` rows are handed back (a residual that exists for those rows alone)
+            if x2.data_ptr() != x.data_ptr() or not 0 < last <= m:
+                raise ValueError("layer_norm_last: the input must be contiguous and hold at least `last` rows")
+            return y.view(*lead, n), x.view(m, n)[m - last:]
         return y.view(*lead, n), x.view_as(x)
 
     @staticmethod
@@ -1138,13 +1143,17 @@ class _LayerNorm(torch.autograd.Function):
         m, n = x2.shape
         dev = x2.device
         if dy is None:  # only the pass-through output was used
-            return dres, None, None, None
+            if ctx.last:
+                raise RuntimeError("layer_norm_last: the normalised rows must take part in the graph")
+            return dres, None, None, None, None
         dy2 = _rows2(dy)
-        add2 = _rows2(dres) if dres is not None else None
+        add2 = _rows2(dres) if (dres is not None and not ctx.last) else None
         dx = torch.empty(m, n, dtype=torch.float32, device=dev)
         dgamma, dbeta = _ln_backward(dy2, x2, x2.stride(0), stats, gamma, beta, 0, m, n, add2, dx, _stream(x2),
                                      ctx.norm_leaves)
-        return dx.view(*ctx.lead, n), dgamma, dbeta, None
+        if ctx.last and dres is not None:  # the residual route's gradient reaches the last rows only
+            dx[m - ctx.last:].add_(_rows2(dres))
+        return dx.view(*ctx.lead, n), dgamma, dbeta, None, None
 
 
 def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm) -> torch.Tensor:
@@ -1167,6 +1176,80 @@ def layer_norm_residual(x: torch.Tensor, norm: torch.nn.LayerNorm) -> Tuple[torc
     if x.shape[-1] > 128 or x.dtype != torch.float32:
         raise _unsupported(f"LayerNorm over {x.shape[-1]} columns of {x.dtype} (float32, at most 128)")
     return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+def layer_norm_last(x: torch.Tensor, norm: torch.nn.LayerNorm, last: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(norm(x), rows)`` with ``rows`` the last ``last`` rows of ``x`` flattened to [rows, width] -- for a block that
+    uses the whole normalised tensor but adds its residual to those rows alone (the temporal encoder's last layer):
+    the residual's gradient joins the LayerNorm's inside one node instead of through a zero-filled full-size tensor."""
+    if x.shape[-1] > 128 or x.dtype != torch.float32:
+        raise _unsupported(f"LayerNorm over {x.shape[-1]} columns of {x.dtype} (float32, at most 128)")
+    return _LayerNorm.apply(x.contiguous(), norm.weight, norm.bias, norm.eps, int(last))
+
+
+class _LastRowQKV(torch.autograd.Function):
+    """``q = xn[-rows:] w[:D]^T + b[:D]`` and ``kv = xn w[D:]^T + b[D:]`` for the fused projection ``w`` [3D, D] of an
+    attention layer whose queries exist for the last ``rows`` rows only: two forward launches; backward writes the
+    key | value route's input gradient, adds the query route's into its last rows in the same launch that computes
+    it, and fills ONE gradient for ``w`` and ``b`` (no slices of parameters in the graph, no zero-filled tensors)."""
+
+    @staticmethod
+    def forward(ctx, xn, w, b, rows):
+        _need_gpu(xn, w, b)
+        x2 = _rows2(xn)
+        m, d = x2.shape
+        if w.shape != (3 * d, d) or b.shape != (3 * d,) or not w.is_contiguous() or not 0 < rows <= m:
+            raise ValueError("last_row_qkv: w must be a contiguous [3D, D] matrix, b [3D]")
+        b = b.contiguous()
+        x_last = x2[m - rows:]
+        q = fused_linear(x_last, w[:d], b[:d])
+        kv = fused_linear(x2, w[d:], b[d:])
+        ctx.save_for_backward(x2, w)
+        ctx.rows = int(rows)
+        ctx.shape = tuple(xn.shape)
+        ctx.leaves = _all_leaves(w, b)
+        return q, kv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dq, dkv):
+        x2, w = ctx.saved_tensors
+        m, d = x2.shape
+        rows, dev, s = ctx.rows, x2.device, _stream(x2)
+        dq, dkv = _rows2(dq), _rows2(dkv)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(m, d, dtype=torch.float32, device=dev)
+            w_kv, tail = w[d:], dx[m - rows:]
+            _lib.call("hivt_linear_bwd_data", _p(dkv), dkv.stride(0), _p(w_kv), w.stride(0), m, 2 * d, d, None, 0, 1.0,
+                      None, 0, _p(dx), d, s)
+            _lib.call("hivt_linear_bwd_data", _p(dq), dq.stride(0), _p(w), w.stride(0), rows, d, d, None, 0, 1.0,
+                      _p(tail), d, _p(tail), d, s)  # (reads and writes the same rows: += in place)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.empty(3 * d, d, dtype=torch.float32, device=dev)
+            db = torch.empty(3 * d, dtype=torch.float32, device=dev)
+            x_last = x2[m - rows:]
+            terms = [(dq, x_last, rows, d, dw.data_ptr(), db.data_ptr()),
+                     (dkv, x2, m, 2 * d, dw.data_ptr() + 4 * d * d, db.data_ptr() + 4 * d)]
+            if _may_defer(ctx.leaves):
+                for i, (g, x, mm, n, dw_at, db_at) in enumerate(terms):
+                    _schedule_flush()
+                    # (the buffers are adopted whole: the check looks at the first term's addresses, the gradient's own)
+                    _deferred.append(([g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), mm, n, d, dw_at, db_at, 0], dev,
+                                      (g, x), ((dw_at, db_at) if i == 0 else (), ctx.leaves)))
+            else:
+                flat = []
+                for g, x, mm, n, dw_at, db_at in terms:
+                    flat += [g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), mm, n, d, dw_at, db_at, 0]
+                _launch_wgrad_group(flat, len(terms), dev)
+        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
+
+
+def last_row_qkv(xn: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Queries of the last ``rows`` rows and key | value rows of all rows of ``xn`` (flattened to [M, D]) under the
+    fused projection ``weight`` [3D, D]: ``(q [rows, D], kv [M, 2D])``."""
+    return _LastRowQKV.apply(xn, weight, bias, int(rows))
 
 
 def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
