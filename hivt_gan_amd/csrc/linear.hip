@@ -545,6 +545,100 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// The same for N = 128 exactly and 16-byte aligned rows: HALF a wave per row (a lane owns four consecutive columns,
+// one 16-byte load per operand), two rows per wave at a time and two such pairs in flight -- half the load
+// instructions per row of the kernel above and one exchange step less in each of the two reductions over a row.
+// Partial sums leave in the same [grid][2][N] layout.
+__global__ __launch_bounds__(256) void ln_bwd128_kernel(const float* __restrict__ dy, int64_t dy_ld,
+                                                        const float* __restrict__ z, int64_t z_ld,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int relu, int64_t M, float* __restrict__ dz, int64_t dz_ld,
+                                                        float* __restrict__ partial /*[grid][2][128]*/,
+                                                        const float* __restrict__ add, int64_t add_ld, int dz_half) {
+  constexpr int N = 128, U = 2;
+  __shared__ float red[8][2][N];  // [wave * 2 + row half][dgamma | dbeta][column]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 5, c0 = (lane & 31) * 4;
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + c0), b4 = *reinterpret_cast<const float4*>(beta + c0);
+  const float g_[4] = {g4.x, g4.y, g4.z, g4.w}, b_[4] = {b4.x, b4.y, b4.z, b4.w};
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  const float inv_n = 1.0f / (float)N;
+  const int64_t stride = (int64_t)gridDim.x * 8;  // rows a pass of the grid covers
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 2; base < M; base += U * stride) {
+    float zz[U][4], dd[U][4], mean[U], rstd[U];
+    bool okr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + sub + u * stride;
+      okr[u] = r < M;
+      const int64_t rc = okr[u] ? r : base;  // (base < M: a row that exists)
+      mean[u] = stats[2 * rc];
+      rstd[u] = stats[2 * rc + 1];
+      const float4 a = *reinterpret_cast<const float4*>(z + rc * z_ld + c0);
+      const float4 b = *reinterpret_cast<const float4*>(dy + rc * dy_ld + c0);
+      zz[u][0] = a.x; zz[u][1] = a.y; zz[u][2] = a.z; zz[u][3] = a.w;
+      dd[u][0] = b.x; dd[u][1] = b.y; dd[u][2] = b.z; dd[u][3] = b.w;
+    }
+    float xh[U][4], gg[U][4], s1[U], s2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s1[u] = 0.0f;
+      s2[u] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = okr[u] ? (zz[u][j] - mean[u]) * rstd[u] : 0.0f;
+        float d = okr[u] ? dd[u][j] : 0.0f;
+        if (relu && !(x * g_[j] + b_[j] > 0.0f)) d = 0.0f;
+        xh[u][j] = x;
+        dg[j] += d * x;
+        db[j] += d;
+        gg[u][j] = d * g_[j];
+        s1[u] += gg[u][j];
+        s2[u] += gg[u][j] * x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s1[u] = group_sum<32>(s1[u]) * inv_n;
+      s2[u] = group_sum<32>(s2[u]) * inv_n;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!okr[u]) continue;
+      const int64_t r = base + sub + u * stride;
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd[u] * (gg[u][j] - s1[u] - xh[u][j] * s2[u]);
+      if (add != nullptr) {  // gradient arriving at the un-normalised input by another route (a residual branch)
+        const float4 e = *reinterpret_cast<const float4*>(add + r * add_ld + c0);
+        o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+      }
+      if (dz_half) {
+        uint2 h;
+        h.x = (unsigned)to_bf16_bits(o[0]) | ((unsigned)to_bf16_bits(o[1]) << 16);
+        h.y = (unsigned)to_bf16_bits(o[2]) | ((unsigned)to_bf16_bits(o[3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dz) + r * dz_ld + c0) = h;
+      } else {
+        *reinterpret_cast<float4*>(dz + r * dz_ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[wave * 2 + sub][0][c0 + j] = dg[j];
+    red[wave * 2 + sub][1][c0 + j] = db[j];
+  }
+  __syncthreads();
+  {  // 256 threads = 2 x 128 sums, the eight row groups added in a fixed order
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    float t = red[0][which][c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q][which][c];
+    partial[((int64_t)blockIdx.x * 2 + which) * N + c] = t;
+  }
+}
+
 // Stand-alone LayerNorm forward: y = gamma * (x - mean) * rstd + beta, one wave per row, two rows in
 // flight; mean / rstd are kept for the backward pass (two-pass variance, as in the fused epilogue).
 template <int NPL>
@@ -615,6 +709,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         for (int j = 0; j < NPL; ++j)
           if (c0 + j < N) y[r * y_ld + c0 + j] = o[j];
       }
+    }
+  }
+}
+
+// N = 128 exactly, 16-byte aligned rows: half a wave per row, four columns per lane (see ln_bwd128_kernel).
+__global__ __launch_bounds__(256) void ln_fwd128_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int64_t M, float* __restrict__ y, int64_t y_ld,
+                                                        float* __restrict__ stats) {
+  constexpr int N = 128, U = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 5, c0 = (lane & 31) * 4;
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + c0), b4 = *reinterpret_cast<const float4*>(beta + c0);
+  const float inv_n = 1.0f / (float)N;
+  const int64_t stride = (int64_t)gridDim.x * 8;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 2; base < M; base += U * stride) {
+    float4 v[U];
+    float s[U], mean[U];
+    bool okr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = base + sub + u * stride;
+      okr[u] = r < M;
+      v[u] = *reinterpret_cast<const float4*>(x + (okr[u] ? r : base) * x_ld + c0);
+      s[u] = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mean[u] = group_sum<32>(s[u]) * inv_n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float d0 = v[u].x - mean[u], d1 = v[u].y - mean[u], d2 = v[u].z - mean[u], d3 = v[u].w - mean[u];
+      s[u] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = rsqrtf(group_sum<32>(s[u]) * inv_n + eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!okr[u]) continue;
+      const int64_t r = base + sub + u * stride;
+      if ((lane & 31) == 0) {
+        stats[2 * r] = mean[u];
+        stats[2 * r + 1] = s[u];
+      }
+      *reinterpret_cast<float4*>(y + r * y_ld + c0) =
+          make_float4((v[u].x - mean[u]) * s[u] * g4.x + b4.x, (v[u].y - mean[u]) * s[u] * g4.y + b4.y,
+                      (v[u].z - mean[u]) * s[u] * g4.z + b4.z, (v[u].w - mean[u]) * s[u] * g4.w + b4.w);
     }
   }
 }
@@ -1336,7 +1476,13 @@ static int ln_bwd_impl(const float* dy, int64_t dy_ld, const float* z, int64_t z
   HIVT_REQUIRE(!dz_half || (al8(dz) && dz_ld % 4 == 0 && N % 4 == 0), HIVT_ERR_ARG,
                "%s: a bfloat16 dz needs N and dz_ld that are multiples of 4 and rows on 8-byte boundaries", what);
   const int vec = (al8(dy) && al8(z) && al8(dz) && dy_ld % 2 == 0 && z_ld % 2 == 0 && dz_ld % 2 == 0) ? 1 : 0;
-  if (N <= 64)
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool wide = N == 128 && al16(dy) && al16(z) && al16(gamma) && al16(beta) && dy_ld % 4 == 0 && z_ld % 4 == 0 &&
+                    dz_ld % 4 == 0 && (dz_half ? al8(dz) : al16(dz)) && (add == nullptr || (al16(add) && add_ld % 4 == 0));
+  if (wide)
+    hipLaunchKernelGGL(ln_bwd128_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma, beta,
+                       relu, M, dz, dz_ld, partial, add, add_ld, dz_half ? 1 : 0);
+  else if (N <= 64)
     hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dy, dy_ld, z, z_ld, stats, gamma,
                        beta, relu, M, N, vec, dz, dz_ld, partial, add, add_ld, dz_half ? 1 : 0);
   else
@@ -1411,7 +1557,11 @@ extern "C" int hivt_ln_fwd(const float* x, int64_t x_ld, const float* gamma, con
   auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
   const int vec = (al8(x) && al8(y) && x_ld % 2 == 0 && y_ld % 2 == 0) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 64)
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (N == 128 && al16(x) && al16(y) && al16(gamma) && al16(beta) && x_ld % 4 == 0 && y_ld % 4 == 0)
+    hipLaunchKernelGGL(ln_fwd128_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, gamma, beta, eps, M, y, y_ld,
+                       stats);
+  else if (N <= 64)
     hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, gamma, beta, eps, M, N, vec,
                        y, y_ld, stats);
   else
