@@ -83,6 +83,15 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
     bet[j] = okc[j] ? a.beta[gc] : 0.0f;
   }
   const float inv_n = 1.0f / (float)a.N;
+  // Full 128-column rows with 16-byte aligned outputs take two phases: the row statistics exactly as below (a wave
+  // per row, the same sums in the same order, so results do not depend on the route), with the finished pre-norm
+  // values and the statistics left in LDS; then the rows leave four columns per thread -- one 16-byte store per
+  // output and row instead of two 4-byte ones per lane and row (these epilogues are bound by the issue of their
+  // stores).
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool wide = BN == 128 && a.N == 128 && col0 == 0 && al16(a.y) && a.y_ld % 4 == 0 &&
+                    (a.z == nullptr || (al16(a.z) && a.z_ld % 4 == 0));
+  __shared__ float row_stats[BM][2];
   for (int r = wave; r < BM; r += 8) {
     constexpr int U = 2;  // rows r and r + 4 together: two independent reduction chains
     float vals[U][CPL], sum[U];
@@ -121,6 +130,20 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) rstd[u] = rsqrtf(wave_sum(sum[u]) * inv_n + a.eps);
+    if (wide) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + 4 * u;
+        if (rr >= BM) continue;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) lds[rr * C::C_PITCH + lane + 64 * j] = vals[u][j];
+        if (lane == 0) {
+          row_stats[rr][0] = mean[u];
+          row_stats[rr][1] = rstd[u];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!okr[u]) continue;
@@ -138,6 +161,37 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
         if (EPI == EPI_LN_RELU) o = fmaxf(o, 0.0f);
         a.y[gr * a.y_ld + gc] = o;
       }
+    }
+  }
+  if (wide) {
+    __syncthreads();
+    const int c4 = (threadIdx.x & 31) * 4, rsub = threadIdx.x >> 5;
+    float gam4[4], bet4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gam4[j] = a.gamma[c4 + j];
+      bet4[j] = a.beta[c4 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < BM / 8; ++i) {
+      const int rr = rsub + 8 * i;
+      const int64_t gr = row0 + rr;
+      if (gr >= a.M) continue;
+      const float4 t = *reinterpret_cast<const float4*>(lds + rr * C::C_PITCH + c4);
+      const float v[4] = {t.x, t.y, t.z, t.w};
+      const float mean = row_stats[rr][0], rstd = row_stats[rr][1];
+      if (c4 == 0 && a.stats) {
+        a.stats[2 * gr] = mean;
+        a.stats[2 * gr + 1] = rstd;
+      }
+      if (a.z) *reinterpret_cast<float4*>(a.z + gr * a.z_ld + c4) = t;
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (v[j] - mean) * rstd * gam4[j] + bet4[j];
+        if (EPI == EPI_LN_RELU) o[j] = fmaxf(o[j], 0.0f);
+      }
+      *reinterpret_cast<float4*>(a.y + gr * a.y_ld + c4) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
