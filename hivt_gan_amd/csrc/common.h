@@ -94,23 +94,42 @@ int linear_bwd_data_gated(const float* dy, int64_t dy_ld, const float* w, int64_
                           int64_t dx_ld, hivt_stream_t stream);
 
 // ---- device helpers -------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// The value of lane (lane ^ O).  Offsets 1 and 2 stay inside a quad and offset 8 inside a row of 16 lanes, where the
+// data-parallel-primitive operand modifiers move them at full rate inside the vector unit; every other offset goes
+// through the LDS crossbar.  ROTATE4: the caller guarantees that lanes l and l ^ 8 hold the same value (the state
+// right after the offset-8 step of a butterfly), which makes a rotation by 4 inside the row deliver the value of
+// lane l ^ 4.  All lanes of a group must be active together, as with the crossbar version.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int O, bool ROTATE4 = false>
+__device__ __forceinline__ float lane_xor(float v) {
+  if constexpr (O == 1) return dpp_move<0xB1>(v);        // quad_perm:[1,0,3,2]
+  else if constexpr (O == 2) return dpp_move<0x4E>(v);   // quad_perm:[2,3,0,1]
+  else if constexpr (O == 8) return dpp_move<0x128>(v);  // row_ror:8
+  else if constexpr (O == 4 && ROTATE4) return dpp_move<0x124>(v);  // row_ror:4
+  else return __shfl_xor(v, O, 64);
+}
+
+// Sum over the aligned group of GROUP consecutive lanes (GROUP a power of two <= 64): the butterfly
+// v += v[lane ^ o] for o = GROUP/2 ... 1, every lane ending with the same bits.
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (GROUP >= 64) v += lane_xor<32>(v);
+  if constexpr (GROUP >= 32) v += lane_xor<16>(v);
+  if constexpr (GROUP >= 16) v += lane_xor<8>(v);
+  if constexpr (GROUP >= 8) v += lane_xor<4, GROUP >= 16>(v);
+  if constexpr (GROUP >= 4) v += lane_xor<2>(v);
+  if constexpr (GROUP >= 2) v += lane_xor<1>(v);
   return v;
 }
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// Sum over the aligned group of GROUP consecutive lanes (GROUP a power of two <= 64).
-template <int GROUP>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -125,8 +144,9 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t index) {
 }
 
 // The same for a 32-bit index: three 32-bit multiplies instead of three 64-bit ones, for kernels that
-// draw many numbers per loaded byte (the temporal attention draws one per score).
-__device__ __forceinline__ float uniform01_u32(uint64_t seed, uint32_t index) {
+// draw many numbers per loaded byte (the temporal attention draws one per score).  uniform_bits24 is the
+// draw as an integer in [0, 2^24), uniform01_u32 the same draw scaled to [0, 1).
+__device__ __forceinline__ uint32_t uniform_bits24(uint64_t seed, uint32_t index) {
   uint32_t x = index ^ (uint32_t)seed;
   x *= 0x9E3779B1u;
   x ^= x >> 15;
@@ -135,7 +155,10 @@ __device__ __forceinline__ float uniform01_u32(uint64_t seed, uint32_t index) {
   x ^= x >> 13;
   x *= 0xC2B2AE35u;
   x ^= x >> 16;
-  return (float)(x >> 8) * (1.0f / 16777216.0f);
+  return x >> 8;
+}
+__device__ __forceinline__ float uniform01_u32(uint64_t seed, uint32_t index) {
+  return (float)uniform_bits24(seed, index) * (1.0f / 16777216.0f);
 }
 
 // Draw of the dropout masks of the dense layers' epilogues (and of the kernel that applies the same mask to the

@@ -54,6 +54,10 @@ struct SegAttnArgs {
   float* dv;
   int64_t dkv_stride;
   int32_t dkv_half;  // dk / dv point at bfloat16 elements (dkv_stride counts them); values rounded to nearest even
+  int32_t zero_tail;   // backward: rows [rowptr[N], E_cap) of dk / dv are zeroed by extra blocks of the same launch
+  int32_t row_blocks;  // backward: blocks that serve targets; the blocks after them zero the tail
+  int64_t E_cap;
+  int32_t narrow;      // every K / V / dK / dV row starts below 4 GiB: 32-bit byte offsets
   // optional: events that receive the kernel's own start / stop time stamps
   hipEvent_t ev_start;
   hipEvent_t ev_stop;
@@ -86,6 +90,35 @@ __device__ __forceinline__ float4 shfl_xor4(const float4& a, int o) {
   return make_float4(__shfl_xor(a.x, o, 64), __shfl_xor(a.y, o, 64), __shfl_xor(a.z, o, 64), __shfl_xor(a.w, o, 64));
 }
 
+// Byte offsets into the K / V / dK / dV rows.  NARROW: every row of those tensors starts below 4 GiB (the entry
+// points check it), so an offset is one 32-bit register added to the tensor's base address by the load itself,
+// and consecutive edges of a batch differ by a wave-uniform step -- a few integer instructions per edge where 64-bit
+// row * stride products took a dozen.
+template <bool NARROW>
+struct OffsetType {
+  using type = uint64_t;
+};
+template <>
+struct OffsetType<true> {
+  using type = uint32_t;
+};
+template <typename Off>
+__device__ __forceinline__ float4 ldg4_at(const float* base, Off off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+}
+template <typename Off>
+__device__ __forceinline__ char* byte_at(float* base, Off off) {
+  return reinterpret_cast<char*>(base) + off;
+}
+
+// Dropout decision of (edge, head) number idx: the 24 random bits of the 32-bit mix against p * 2^24 rounded up,
+// which is the comparison uniform >= p done on integers.
+template <typename Idx>
+__device__ __forceinline__ bool keep_draw(uint64_t seed, Idx idx, uint32_t threshold) {
+  if constexpr (sizeof(Idx) == 8) seed += (uint64_t)(idx >> 32) * 0x9E3779B97F4A7C15ull;
+  return uniform_bits24(seed, (uint32_t)idx) >= threshold;
+}
+
 // Merge two online-softmax states (m, l, acc) <- (m, l, acc) (+) (m2, l2, acc2).
 __device__ __forceinline__ void merge_state(float& m, float& l, float4& acc, float m2, float l2, const float4& acc2) {
   const float mn = fmaxf(m, m2);
@@ -107,7 +140,7 @@ constexpr int kRowsInterleaved = 2;  // step-major rows: the j-th edge of target
 // WPN  = waves that share one target row (1, or 4 for long rows, merged through LDS)
 // SPLIT = short-row mode: every lane slot (LPR lanes) of a wave owns its OWN target row, so a wave
 //         serves 64/LPR rows at once and no slot merge is needed (requires WPN == 1)
-template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL>
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL, bool NARROW>
 __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) {
   constexpr bool GLOBAL = KIND == kRowsNodeTerms;
   constexpr bool INTERLEAVED = KIND == kRowsInterleaved;
@@ -116,6 +149,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   constexpr int NPB = 4 / WPN;  // row groups per 256-thread block
   constexpr int RPW = SPLIT ? EPI : 1;
   constexpr int kUnroll = UNROLL;
+  using Off = typename OffsetType<NARROW>::type;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 6 : 1];
 
@@ -130,41 +164,52 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
 
+  // A row's memory latencies in a row are two, not three: its bounds, then its first batch of K / V rows.  The query
+  // is requested with the bounds where most rows have edges (every mode but the short-row one, which asks only for
+  // rows that have edges: there most rows are empty), and it is first used after the first batch has been requested.
   const int beg = a.rowptr[nc];
   int end = row_ok ? a.rowptr[nc + 1] : beg;
-  if (INTERLEAVED) end = min(end, beg + a.seg_len);
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (end > beg) {  // rows without edges never need their query
-    qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
-    scale4(qs, a.scale_inv);
-  }
+  if constexpr (!SPLIT) qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+  if (INTERLEAVED) end = min(end, beg + a.seg_len);
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint32_t threshold = (uint32_t)ceilf(a.dropout_p * 16777216.0f);
   const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
 
   float m = kNegSentinel, l = 0.0f;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   constexpr int STRIDE = SPLIT ? 1 : WPN * EPI;
-  const int first = SPLIT ? beg : beg + win * EPI + sub;
-  for (int e0 = first; e0 < end; e0 += STRIDE * kUnroll) {
-    float4 kk[kUnroll], vv[kUnroll];
-    float s[kUnroll];
-    bool ok[kUnroll];
+  const Off row_bytes = (Off)a.kv_stride * 4;
+  const Off step = (INTERLEAVED ? row_bytes * (Off)a.row_interleave : row_bytes) * STRIDE;  // to the next edge of a slot
+  float4 kk[kUnroll], vv[kUnroll];
+  bool ok[kUnroll];
+  int e0 = SPLIT ? beg : beg + win * EPI + sub;
+  auto request_batch = [&]() {
+    const Off r0 = INTERLEAVED ? (Off)(e0 - beg) * (Off)a.row_interleave + (Off)nc : (Off)e0;
+    const Off at0 = r0 * row_bytes + 16 * c;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const int e = e0 + u * STRIDE;
-      ok[u] = e < end;
-      const int64_t ee = ok[u] ? e : e0;
-      const int64_t er = INTERLEAVED ? (ee - beg) * a.row_interleave + nc : ee;
-      kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
-      vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
+      ok[u] = e0 + u * STRIDE < end;
+      const Off at = ok[u] ? at0 + (Off)u * step : at0;
+      kk[u] = ldg4_at(a.k, at);
+      vv[u] = ldg4_at(a.v, at);
       if (GLOBAL) {
-        const int64_t j = a.src[ee];
+        const int64_t j = a.src[ok[u] ? e0 + u * STRIDE : e0];
         kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
         vv[u] = add4(vv[u], ldg4(a.v_node + j * a.node_stride + 4 * c));
       }
     }
+  };
+  bool more = e0 < end;
+  if (more) {
+    if constexpr (SPLIT) qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+    request_batch();
+  }
+  scale4(qs, a.scale_inv);
+  while (more) {
+    float s[kUnroll];
     float smax = m;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -176,16 +221,17 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
     l *= corr;
     scale4(acc, corr);
     m = smax;
+    const Off idx0 = (Off)e0 * (Off)a.H + (Off)h;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       float p = ok[u] ? fast_exp(s[u] - m) : 0.0f;
       l += p;
-      if (drop) {
-        const uint64_t idx = (uint64_t)(e0 + u * STRIDE) * (uint64_t)a.H + (uint64_t)h;
-        p = uniform01(seed, idx) >= a.dropout_p ? p * keep_scale : 0.0f;
-      }
+      if (drop) p = keep_draw<Off>(seed, idx0 + (Off)(u * STRIDE) * (Off)a.H, threshold) ? p * keep_scale : 0.0f;
       fma4(acc, p, vv[u]);
     }
+    e0 += STRIDE * kUnroll;
+    more = e0 < end;
+    if (more) request_batch();
   }
 
   if (!SPLIT) {
@@ -230,13 +276,37 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
 }
 
 // four values as bfloat16 (nearest even) in 8 bytes
+typedef __bf16 bf16_pair __attribute__((ext_vector_type(2)));
+typedef float f32_pair __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 pack_bf16x4(float x, float y, float z, float w) {
-  auto bits = [](float v) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v); };
-  return make_uint2(bits(x) | (bits(y) << 16), bits(z) | (bits(w) << 16));
+  const f32_pair lo = {x, y}, hi = {z, w};
+  return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16_pair)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16_pair)));
 }
 
-// HALF: dk / dv are bfloat16 rows (a compile-time switch: the fp32 kernels keep their code as it was)
-template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL, bool HALF = false>
+// Blocks past the row groups zero rows [rowptr[N], E_cap) of dk / dv, which belong to no target (fixed-capacity edge
+// lists): everything upstream of the projection then sees exact zeros for the padding.
+constexpr int kTailBlocks = 128;
+template <int D, bool HALF>
+__device__ __forceinline__ void zero_tail_rows(const SegAttnArgs& a, int block, int blocks) {
+  constexpr int QUADS = D / 4;
+  const int64_t live = a.rowptr[a.N];
+  const int64_t total = (a.E_cap - live) * QUADS;
+  for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < total; i += (int64_t)blocks * 256) {
+    const int64_t e = live + i / QUADS;
+    const int c = (int)(i % QUADS) * 4;
+    if constexpr (HALF) {  // bfloat16 rows: four zeros are 8 bytes
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dk) + e * a.dkv_stride + c) = make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dv) + e * a.dkv_stride + c) = make_uint2(0u, 0u);
+    } else {
+      *reinterpret_cast<float4*>(a.dk + e * a.dkv_stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(a.dv + e * a.dkv_stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// HALF: dk / dv are bfloat16 rows (a compile-time switch: the fp32 kernels keep their arithmetic as it was)
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL, bool HALF, bool NARROW>
 __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) {
   constexpr bool GLOBAL = KIND == kRowsNodeTerms;
   constexpr bool INTERLEAVED = KIND == kRowsInterleaved;
@@ -245,9 +315,14 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   constexpr int NPB = 4 / WPN;
   constexpr int RPW = SPLIT ? EPI : 1;
   constexpr int kUnroll = UNROLL;
+  using Off = typename OffsetType<NARROW>::type;
   static_assert(!SPLIT || WPN == 1, "short-row mode is single-wave");
   __shared__ float smem[WPN > 1 ? 4 * LPR * 4 : 1];
 
+  if ((int)blockIdx.x >= a.row_blocks) {  // whole blocks: none of them reaches a barrier
+    zero_tail_rows<D, HALF>(a, (int)blockIdx.x - a.row_blocks, (int)gridDim.x - a.row_blocks);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int sub = lane / LPR;
@@ -259,75 +334,90 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
 
+  // As in the forward kernel: the row's own operands travel with its bounds (or, in the short-row mode, with its
+  // first batch) and are first used once that batch has been requested.
   const int beg = a.rowptr[nc];
   int end = row_ok ? a.rowptr[nc + 1] : beg;
-  if (INTERLEAVED) end = min(end, beg + a.seg_len);
-  float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs;
-  float delta = 0.0f, mh = 0.0f, inv_den = 0.0f;
-  if (end > beg) {
+  float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs, o4 = qs;
+  float mh = 0.0f, den = 1.0f;
+  auto request_row = [&]() {
     qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
-    scale4(qs, a.scale_inv);
     go = ldg4(a.d_out + (int64_t)nc * D + 4 * c);
-    const float4 o4 = ldg4(a.out + (int64_t)nc * D + 4 * c);
-    delta = group_sum<LPH>(dot4(go, o4));
+    o4 = ldg4(a.out + (int64_t)nc * D + 4 * c);
     mh = a.m[(int64_t)nc * a.H + h];
-    inv_den = 1.0f / a.den[(int64_t)nc * a.H + h];
-  }
+    den = a.den[(int64_t)nc * a.H + h];
+  };
+  if constexpr (!SPLIT) request_row();
+  if (INTERLEAVED) end = min(end, beg + a.seg_len);
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+  const uint32_t threshold = (uint32_t)ceilf(a.dropout_p * 16777216.0f);
   const uint64_t seed = a.seed + ((drop && a.seed_ptr) ? *a.seed_ptr : 0ull);
 
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
 
   constexpr int STRIDE = SPLIT ? 1 : WPN * EPI;
-  const int first = SPLIT ? beg : beg + win * EPI + sub;
-  for (int e0 = first; e0 < end; e0 += STRIDE * kUnroll) {
-    float4 kk[kUnroll], vv[kUnroll];
-    bool ok[kUnroll];
+  const Off row_bytes = (Off)a.kv_stride * 4;
+  const Off grad_bytes = (Off)a.dkv_stride * (HALF ? 2 : 4);
+  const Off interleave = INTERLEAVED ? (Off)a.row_interleave : (Off)1;
+  const Off step = row_bytes * interleave * STRIDE, grad_step = grad_bytes * interleave * STRIDE;
+  float4 kk[kUnroll], vv[kUnroll];
+  bool ok[kUnroll];
+  Off r0 = 0;
+  int e0 = SPLIT ? beg : beg + win * EPI + sub;
+  auto request_batch = [&]() {
+    r0 = INTERLEAVED ? (Off)(e0 - beg) * interleave + (Off)nc : (Off)e0;
+    const Off at0 = r0 * row_bytes + 16 * c;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const int e = e0 + u * STRIDE;
-      ok[u] = e < end;
-      const int64_t ee = ok[u] ? e : e0;
-      const int64_t er = INTERLEAVED ? (ee - beg) * a.row_interleave + nc : ee;
-      kk[u] = ldg4(a.k + er * a.kv_stride + 4 * c);
-      vv[u] = ldg4(a.v + er * a.kv_stride + 4 * c);
+      ok[u] = e0 + u * STRIDE < end;
+      const Off at = ok[u] ? at0 + (Off)u * step : at0;
+      kk[u] = ldg4_at(a.k, at);
+      vv[u] = ldg4_at(a.v, at);
       if (GLOBAL) {
-        const int64_t j = a.src[ee];
+        const int64_t j = a.src[ok[u] ? e0 + u * STRIDE : e0];
         kk[u] = add4(kk[u], ldg4(a.k_node + j * a.node_stride + 4 * c));
         vv[u] = add4(vv[u], ldg4(a.v_node + j * a.node_stride + 4 * c));
       }
     }
+  };
+  bool more = e0 < end;
+  if (more) {
+    if constexpr (SPLIT) request_row();
+    request_batch();
+  }
+  scale4(qs, a.scale_inv);
+  const float delta = group_sum<LPH>(dot4(go, o4));
+  const float inv_den = 1.0f / den;
+  while (more) {
+    const Off idx0 = (Off)e0 * (Off)a.H + (Off)h;
+    const Off grad0 = r0 * grad_bytes + (HALF ? 8 : 16) * c;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const float s = group_sum<LPH>(dot4(qs, kk[u]));
       const float dav = group_sum<LPH>(dot4(go, vv[u]));
       if (ok[u]) {
-        const int64_t e = e0 + u * STRIDE;
         const float alpha = fast_exp(s - mh) * inv_den;
         float ms = 1.0f;
-        if (drop) {
-          const uint64_t idx = (uint64_t)e * (uint64_t)a.H + (uint64_t)h;
-          ms = uniform01(seed, idx) >= a.dropout_p ? keep_scale : 0.0f;
-        }
+        if (drop) ms = keep_draw<Off>(seed, idx0 + (Off)(u * STRIDE) * (Off)a.H, threshold) ? keep_scale : 0.0f;
         const float am = alpha * ms;
         const float ds = alpha * (dav * ms - delta);
-        const int64_t er = INTERLEAVED ? (e - beg) * a.row_interleave + nc : e;
+        const Off at = grad0 + (Off)u * grad_step;
         if constexpr (HALF) {
-          const int64_t at = er * a.dkv_stride + 4 * c;
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dv) + at) =
-              pack_bf16x4(am * go.x, am * go.y, am * go.z, am * go.w);
-          *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.dk) + at) =
-              pack_bf16x4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+          const uint2 pv = pack_bf16x4(am * go.x, am * go.y, am * go.z, am * go.w);
+          const uint2 pk = pack_bf16x4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+          *reinterpret_cast<uint2*>(byte_at(a.dv, at)) = pv;
+          *reinterpret_cast<uint2*>(byte_at(a.dk, at)) = pk;
         } else {
-          *reinterpret_cast<float4*>(a.dv + er * a.dkv_stride + 4 * c) =
-              make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
-          *reinterpret_cast<float4*>(a.dk + er * a.dkv_stride + 4 * c) =
-              make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
+          *reinterpret_cast<float4*>(byte_at(a.dv, at)) = make_float4(am * go.x, am * go.y, am * go.z, am * go.w);
+          *reinterpret_cast<float4*>(byte_at(a.dk, at)) = make_float4(ds * qs.x, ds * qs.y, ds * qs.z, ds * qs.w);
         }
         fma4(dq, ds, kk[u]);
       }
     }
+    e0 += STRIDE * kUnroll;
+    more = e0 < end;
+    if (more) request_batch();
   }
 
   if (!SPLIT) {
@@ -348,70 +438,51 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   }
 }
 
-// Rows [rowptr[N], E_cap) of dk / dv belong to no target (fixed-capacity edge lists): zero them so
-// that everything upstream of the projection sees exact zeros for the padding.
-__global__ __launch_bounds__(256) void zero_tail_kernel(const int32_t* __restrict__ rowptr, int32_t N, int64_t E_cap,
-                                                        int32_t D, float* __restrict__ dk, float* __restrict__ dv,
-                                                        int64_t stride, int half) {
-  const int64_t live = rowptr[N];
-  const int64_t quads = D / 4;
-  const int64_t total = (E_cap - live) * quads;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = live + i / quads;
-    const int c = (int)(i % quads) * 4;
-    if (half) {  // bfloat16 rows: four zeros are 8 bytes
-      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dk) + e * stride + c) = make_uint2(0u, 0u);
-      *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dv) + e * stride + c) = make_uint2(0u, 0u);
-    } else {
-      *reinterpret_cast<float4*>(dk + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(dv + e * stride + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-}
-
-template <int D, int LPH, int WPN, int GLOBAL, bool SPLIT, int UNROLL>
-int launch_one(bool backward, const SegAttnArgs& a, hipStream_t stream) {
-  constexpr int NPB = 4 / WPN;
-  constexpr int RPW = SPLIT ? kWave / (D / 4) : 1;
-  const unsigned grid = (unsigned)((a.N + NPB * RPW - 1) / (NPB * RPW));
+template <typename Kernel>
+void launch_kernel(Kernel kernel, unsigned grid, const SegAttnArgs& a, hipStream_t stream) {
   if (a.ev_start != nullptr) {
     // the kernel's argument block does not need the host-side event handles
     SegAttnArgs k = a;
     k.ev_start = nullptr;
     k.ev_stop = nullptr;
-    if (backward && a.dkv_half) {
-      if constexpr (GLOBAL == kRowsPlain)
-        hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL, true>), dim3(grid), dim3(256), 0,
-                              stream, a.ev_start, a.ev_stop, 0, k);
-      else
-        return -1;
-    } else if (backward)
-      hipExtLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream,
-                            a.ev_start, a.ev_stop, 0, k);
-    else
-      hipExtLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream,
-                            a.ev_start, a.ev_stop, 0, k);
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, a.ev_start, a.ev_stop, 0, k);
+  } else {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, a);
+  }
+}
+
+template <int D, int LPH, int WPN, int KIND, bool SPLIT, int UNROLL, bool NARROW>
+int launch_one(bool backward, SegAttnArgs a, hipStream_t stream) {
+  constexpr int NPB = 4 / WPN;
+  constexpr int RPW = SPLIT ? kWave / (D / 4) : 1;
+  const unsigned grid = (unsigned)((a.N + NPB * RPW - 1) / (NPB * RPW));
+  if (!backward) {
+    launch_kernel(seg_attn_fwd_kernel<D, LPH, WPN, KIND, SPLIT, UNROLL, NARROW>, grid, a, stream);
     return 0;
   }
-  if (backward && a.dkv_half) {
+  a.row_blocks = (int32_t)grid;
+  const unsigned all = grid + (a.zero_tail ? kTailBlocks : 0);
+  if (a.dkv_half) {
     // bfloat16 dk / dv: built for plain rows (no node terms, not interleaved)
-    if constexpr (GLOBAL == kRowsPlain)
-      hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL, true>), dim3(grid), dim3(256), 0, stream,
-                         a);
+    if constexpr (KIND == kRowsPlain)
+      launch_kernel(seg_attn_bwd_kernel<D, LPH, WPN, KIND, SPLIT, UNROLL, true, NARROW>, all, a, stream);
     else
       return -1;
-  } else if (backward)
-    hipLaunchKernelGGL((seg_attn_bwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((seg_attn_fwd_kernel<D, LPH, WPN, GLOBAL, SPLIT, UNROLL>), dim3(grid), dim3(256), 0, stream, a);
+  } else {
+    launch_kernel(seg_attn_bwd_kernel<D, LPH, WPN, KIND, SPLIT, UNROLL, false, NARROW>, all, a, stream);
+  }
   return 0;
 }
 
 template <int D, int LPH, int WPN, bool SPLIT, int UNROLL>
 int launch_g(bool backward, bool global, const SegAttnArgs& a, hipStream_t stream) {
-  if (global) return launch_one<D, LPH, WPN, kRowsNodeTerms, SPLIT, UNROLL>(backward, a, stream);
-  if (a.row_interleave) return launch_one<D, LPH, WPN, kRowsInterleaved, SPLIT, UNROLL>(backward, a, stream);
-  return launch_one<D, LPH, WPN, kRowsPlain, SPLIT, UNROLL>(backward, a, stream);
+#define HIVT_KIND(KIND_)                                                                           \
+  return a.narrow ? launch_one<D, LPH, WPN, KIND_, SPLIT, UNROLL, true>(backward, a, stream)       \
+                  : launch_one<D, LPH, WPN, KIND_, SPLIT, UNROLL, false>(backward, a, stream);
+  if (global) { HIVT_KIND(kRowsNodeTerms) }
+  if (a.row_interleave) { HIVT_KIND(kRowsInterleaved) }
+  HIVT_KIND(kRowsPlain)
+#undef HIVT_KIND
 }
 
 // Launch shapes.  `waves`: 0 = one target row per lane slot (short rows), 1 / 2 / 4 = waves of a block that
@@ -422,13 +493,13 @@ struct Shape {
 };
 
 // By average row length (measured on 1.3-, 18- and 54-edge rows at D = 128): rows shorter than two unrolled
-// passes of a lane slot go one per slot; long rows are split over the 4 waves of a block with 8 edges in
+// passes of a lane slot go one per slot (two edges in flight forward, four backward); long rows are split over the 4 waves of a block with 8 edges in
 // flight per slot; rows in between take one wave and a short batch forward, but four waves backward, where
 // every edge also costs two stores and the wider split keeps more of them in flight.
 Shape default_shape(int64_t E, int32_t N, bool backward) {
   const int64_t avg = N > 0 ? E / N : 0;
   if (avg >= 48) return {4, kUnrollWide};
-  if (avg < 8) return {0, kUnrollShort};
+  if (avg < 8) return {0, backward ? 4 : kUnrollShort};
   return backward ? Shape{4, 4} : Shape{1, 2};
 }
 
@@ -441,6 +512,7 @@ int launch_dl(bool backward, Shape sh, bool global, const SegAttnArgs& a, hipStr
     // the three default shapes exist for every row width
     HIVT_SHAPE(4, false, kUnrollWide)
     HIVT_SHAPE(1, true, kUnrollShort)
+    HIVT_SHAPE(1, true, 4)
     HIVT_SHAPE(1, false, kUnrollLong)
     HIVT_SHAPE(4, false, 4)
     HIVT_SHAPE(1, false, 2)
@@ -450,7 +522,6 @@ int launch_dl(bool backward, Shape sh, bool global, const SegAttnArgs& a, hipStr
       HIVT_SHAPE(2, false, 4)
       HIVT_SHAPE(2, false, 8)
       HIVT_SHAPE(1, false, 8)
-      HIVT_SHAPE(1, true, 4)
       HIVT_SHAPE(1, true, 8)
     }
 #undef HIVT_SHAPE
@@ -492,6 +563,12 @@ int dispatch(int D, int H, bool backward, int64_t E, bool global, int hint, cons
     case 256: return launch_d<256>(lph, backward, sh, global, a, stream);
     default: return -1;
   }
+}
+
+// rows * stride elements of `bytes` each end below 4 GiB, and so does the (edge, head) counter of the dropout draw
+// (heads * 4 <= stride)
+int fits_32bit(int64_t rows, int64_t stride, int bytes) {
+  return rows * stride * bytes <= (int64_t)0xFFFFFFFFll ? 1 : 0;
 }
 
 int check_shape(const char* what, int32_t N, int64_t E, int32_t D, int32_t H, int64_t kv_stride, int dtype,
@@ -544,6 +621,7 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   a.scale_inv = 1.0f / sqrtf((float)(D / H));
   a.dropout_p = dropout_p; a.seed = seed; a.seed_ptr = seed_ptr;
   a.out = out; a.m = m_out; a.den = den_out;
+  a.narrow = fits_32bit(E, kv_stride, 4);
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, false, E, global, dtype, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d (launch-shape hint 0x%x)", what, D, H, dtype >> 8);
@@ -607,15 +685,13 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
                "%s: bfloat16 dk / dv are built for plain rows only (no node terms, not interleaved)", what);
   HIVT_REQUIRE(!a.dkv_half || E == 0 || ((reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 7) == 0,
                HIVT_ERR_ARG, "%s: bfloat16 dk / dv rows must start on 8-byte boundaries", what);
+  a.zero_tail = (zero_tail && E > 0) ? 1 : 0;
+  a.E_cap = E;
+  a.narrow = fits_32bit(E, kv_stride, 4) && fits_32bit(E, dkv_stride, a.dkv_half ? 2 : 4);
   a.ev_start = (hipEvent_t)ev_start; a.ev_stop = (hipEvent_t)ev_stop;
   HIVT_REQUIRE(dispatch(D, H, true, E, global, dtype, a, (hipStream_t)stream) == 0, HIVT_ERR_ARG,
                "%s: no kernel for D=%d H=%d (launch-shape hint 0x%x)", what, D, H, dtype >> 8);
   HIVT_CHECK_LAUNCH(what);
-  if (zero_tail && E > 0) {
-    hipLaunchKernelGGL(zero_tail_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, rowptr, N, E, D, dk, dv,
-                       dkv_stride, a.dkv_half);
-    HIVT_CHECK_LAUNCH(what);
-  }
   return HIVT_OK;
 }
 
