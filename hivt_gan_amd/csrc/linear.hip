@@ -83,15 +83,89 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
     bet[j] = okc[j] ? a.beta[gc] : 0.0f;
   }
   const float inv_n = 1.0f / (float)a.N;
-  // Full 128-column rows with 16-byte aligned outputs take two phases: the row statistics exactly as below (a wave
-  // per row, the same sums in the same order, so results do not depend on the route), with the finished pre-norm
-  // values and the statistics left in LDS; then the rows leave four columns per thread -- one 16-byte store per
-  // output and row instead of two 4-byte ones per lane and row (these epilogues are bound by the issue of their
-  // stores).
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool wide = BN == 128 && a.N == 128 && col0 == 0 && al16(a.y) && a.y_ld % 4 == 0 &&
                     (a.z == nullptr || (al16(a.z) && a.z_ld % 4 == 0));
-  __shared__ float row_stats[BM][2];
+  if (wide) {
+    // Full 128-column rows with 16-byte aligned outputs: half a wave per row (these epilogues are bound by the
+    // issue of their stores and lane exchanges; a wave per row spends two 4-byte stores per lane and output).
+    // A lane first completes four adjacent columns of the row (bias, added rows) and leaves them in LDS, then
+    // takes columns l, l + 32, l + 64, l + 96 for the statistics: (v[l] + v[l+64]) + (v[l+32] + v[l+96])
+    // followed by the butterfly over 32 lanes is the tree a whole wave builds from v[l] + v[l+64] per lane, so
+    // the statistics have the bits of the wave-per-row route below; the row then leaves with 16-byte stores.
+    const int q = threadIdx.x & 31, half = threadIdx.x >> 5;
+    const int c4 = 4 * q;
+    float gam4[4], bet4[4], bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gam4[j] = a.gamma[c4 + j];
+      bet4[j] = a.beta[c4 + j];
+      bias4[j] = a.t.bias != nullptr ? a.t.bias[c4 + j] : 0.0f;
+    }
+    constexpr int U = 2;  // two rows per half wave in flight
+#pragma unroll 1
+    for (int r = half; r < BM; r += 8 * U) {
+      float v[U][4], mean[U], rstd[U], part[U];
+      bool okr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + 8 * u;
+        const int64_t gr = row0 + rr;
+        okr[u] = gr < a.M;
+        float4 t = *reinterpret_cast<const float4*>(lds + rr * C::C_PITCH + c4);
+        v[u][0] = t.x + bias4[0]; v[u][1] = t.y + bias4[1]; v[u][2] = t.z + bias4[2]; v[u][3] = t.w + bias4[3];
+        if (okr[u] && a.t.add != nullptr) {
+          const int64_t ar = a.t.add_index != nullptr ? min(max(a.t.add_index[gr], 0), a.t.add_rows - 1) : gr;
+          const float4 ad = *reinterpret_cast<const float4*>(a.t.add + ar * a.t.add_ld + c4);
+          v[u][0] += ad.x; v[u][1] += ad.y; v[u][2] += ad.z; v[u][3] += ad.w;
+        }
+        if (!okr[u]) v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.0f;
+        *reinterpret_cast<float4*>(lds + rr * C::C_PITCH + c4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+      }
+      float s[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* row = lds + (r + 8 * u) * C::C_PITCH + q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[u][j] = row[32 * j];
+        float lo = 0.0f, hi = 0.0f;
+        lo += s[u][0]; lo += s[u][2];
+        hi += s[u][1]; hi += s[u][3];
+        part[u] = lo + hi;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mean[u] = group_sum<32>(part[u]) * inv_n;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float lo = 0.0f, hi = 0.0f;
+        { const float d = s[u][0] - mean[u]; lo += d * d; }
+        { const float d = s[u][2] - mean[u]; lo += d * d; }
+        { const float d = s[u][1] - mean[u]; hi += d * d; }
+        { const float d = s[u][3] - mean[u]; hi += d * d; }
+        part[u] = lo + hi;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) rstd[u] = rsqrtf(group_sum<32>(part[u]) * inv_n + a.eps);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!okr[u]) continue;
+        const int64_t gr = row0 + r + 8 * u;
+        if (q == 0 && a.stats) {
+          a.stats[2 * gr] = mean[u];
+          a.stats[2 * gr + 1] = rstd[u];
+        }
+        if (a.z) *reinterpret_cast<float4*>(a.z + gr * a.z_ld + c4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (v[u][j] - mean[u]) * rstd[u] * gam4[j] + bet4[j];
+          if (EPI == EPI_LN_RELU) o[j] = fmaxf(o[j], 0.0f);
+        }
+        *reinterpret_cast<float4*>(a.y + gr * a.y_ld + c4) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    return;
+  }
   for (int r = wave; r < BM; r += 8) {
     constexpr int U = 2;  // rows r and r + 4 together: two independent reduction chains
     float vals[U][CPL], sum[U];
@@ -130,20 +204,6 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) rstd[u] = rsqrtf(wave_sum(sum[u]) * inv_n + a.eps);
-    if (wide) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int rr = r + 4 * u;
-        if (rr >= BM) continue;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) lds[rr * C::C_PITCH + lane + 64 * j] = vals[u][j];
-        if (lane == 0) {
-          row_stats[rr][0] = mean[u];
-          row_stats[rr][1] = rstd[u];
-        }
-      }
-      continue;
-    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!okr[u]) continue;
@@ -161,37 +221,6 @@ __global__ __launch_bounds__(kThreads, TIGHT ? 3 : 1) void linear_fwd_kernel(con
         if (EPI == EPI_LN_RELU) o = fmaxf(o, 0.0f);
         a.y[gr * a.y_ld + gc] = o;
       }
-    }
-  }
-  if (wide) {
-    __syncthreads();
-    const int c4 = (threadIdx.x & 31) * 4, rsub = threadIdx.x >> 5;
-    float gam4[4], bet4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      gam4[j] = a.gamma[c4 + j];
-      bet4[j] = a.beta[c4 + j];
-    }
-#pragma unroll
-    for (int i = 0; i < BM / 8; ++i) {
-      const int rr = rsub + 8 * i;
-      const int64_t gr = row0 + rr;
-      if (gr >= a.M) continue;
-      const float4 t = *reinterpret_cast<const float4*>(lds + rr * C::C_PITCH + c4);
-      const float v[4] = {t.x, t.y, t.z, t.w};
-      const float mean = row_stats[rr][0], rstd = row_stats[rr][1];
-      if (c4 == 0 && a.stats) {
-        a.stats[2 * gr] = mean;
-        a.stats[2 * gr + 1] = rstd;
-      }
-      if (a.z) *reinterpret_cast<float4*>(a.z + gr * a.z_ld + c4) = t;
-      float o[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[j] = (v[j] - mean) * rstd * gam4[j] + bet4[j];
-        if (EPI == EPI_LN_RELU) o[j] = fmaxf(o[j], 0.0f);
-      }
-      *reinterpret_cast<float4*>(a.y + gr * a.y_ld + c4) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
