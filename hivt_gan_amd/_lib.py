@@ -31,15 +31,16 @@ SIGNATURES = {
     "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
     "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
-    "hivt_seg_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32, c_int32,
-                                  c_float, c_uint64, _P, _P, _P, _P, c_int, _P]),
-    "hivt_seg_attn_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64,
-                                  c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int64, c_int32, c_int, _P]),
-    "hivt_seg_attn_fwd_timed": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32,
-                                        c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P, _P, _P]),
-    "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32,
-                                        c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int64,
-                                        c_int32, c_int, _P, _P, _P]),
+    "hivt_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32,
+                                  c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P]),
+    "hivt_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32,
+                                  c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, c_int64, _P, _P, c_int64,
+                                  c_int32, c_int, _P]),
+    "hivt_seg_attn_fwd_timed": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64,
+                                        c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P,
+                                        c_int32, c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, c_int64, _P,
+                                        _P, c_int64, c_int32, c_int, _P, _P, _P]),
     "hivt_segment_sum_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
     "hivt_gated_update_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P]),
     "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,

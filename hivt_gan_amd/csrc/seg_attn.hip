@@ -24,6 +24,7 @@ constexpr int kUnrollShort = 2;  // short-row mode: rows average under two edges
 
 struct SegAttnArgs {
   const float* q;
+  int64_t q_stride, dq_stride;
   const float* k;
   const float* v;
   int64_t kv_stride;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   const int beg = a.rowptr[nc];
   int end = row_ok ? a.rowptr[nc + 1] : beg;
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (!SPLIT) qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+  if constexpr (!SPLIT) qs = ldg4(a.q + (int64_t)nc * a.q_stride + 4 * c);
   if (INTERLEAVED) end = min(end, beg + a.seg_len);
   const bool drop = a.dropout_p > 0.0f;
   const float keep_scale = drop ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   };
   bool more = e0 < end;
   if (more) {
-    if constexpr (SPLIT) qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+    if constexpr (SPLIT) qs = ldg4(a.q + (int64_t)nc * a.q_stride + 4 * c);
     request_batch();
   }
   scale4(qs, a.scale_inv);
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   float4 qs = make_float4(0.f, 0.f, 0.f, 0.f), go = qs, o4 = qs;
   float mh = 0.0f, den = 1.0f;
   auto request_row = [&]() {
-    qs = ldg4(a.q + (int64_t)nc * D + 4 * c);
+    qs = ldg4(a.q + (int64_t)nc * a.q_stride + 4 * c);
     go = ldg4(a.d_out + (int64_t)nc * D + 4 * c);
     o4 = ldg4(a.out + (int64_t)nc * D + 4 * c);
     mh = a.m[(int64_t)nc * a.H + h];
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   }
   if ((SPLIT || sub == 0) && row_ok) {
     scale4(dq, a.scale_inv);
-    *reinterpret_cast<float4*>(a.dq + (int64_t)n * D + 4 * c) = dq;
+    *reinterpret_cast<float4*>(a.dq + (int64_t)n * a.dq_stride + 4 * c) = dq;
   }
 }
 
@@ -594,7 +595,7 @@ int check_shape(const char* what, int32_t N, int64_t E, int32_t D, int32_t H, in
 
 using namespace hivt;
 
-static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+static int seg_attn_fwd_impl(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                              const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
                              int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
                              const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
@@ -609,8 +610,10 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   HIVT_REQUIRE(E == 0 || (k && v), HIVT_ERR_ARG, "%s: null k/v with E > 0", what);
   HIVT_REQUIRE(!global || (v_node && src && node_stride >= D && node_stride % 4 == 0), HIVT_ERR_ARG,
                "%s: node terms need v_node, src and a 16-B aligned node_stride >= D", what);
+  HIVT_REQUIRE(q_stride >= D && q_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0, HIVT_ERR_ARG,
+               "%s: q_stride must be >= D and the query rows 16-B aligned", what);
   SegAttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
+  a.q = q; a.q_stride = q_stride; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
   if (dtype & HIVT_ROWS_INTERLEAVED) {
@@ -629,31 +632,32 @@ static int seg_attn_fwd_impl(const float* q, const float* k, const float* v, int
   return HIVT_OK;
 }
 
-extern "C" int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride,
+extern "C" int hivt_seg_attn_fwd(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                                  const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                                  const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
                                  uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out,
                                  int dtype, hivt_stream_t stream) {
-  return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
-                           seed_ptr, out, m_out, den_out, dtype, stream, nullptr, nullptr);
+  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H,
+                           dropout_p, seed, seed_ptr, out, m_out, den_out, dtype, stream, nullptr, nullptr);
 }
 
-extern "C" int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride,
-                                       const float* k_node, const float* v_node, int64_t node_stride,
-                                       const int32_t* src, const int32_t* rowptr, int32_t N, int64_t E, int32_t D,
-                                       int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
-                                       float* out, float* m_out, float* den_out, int dtype, hivt_stream_t stream,
-                                       void* start_event, void* stop_event) {
-  return seg_attn_fwd_impl(q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H, dropout_p, seed,
-                           seed_ptr, out, m_out, den_out, dtype, stream, start_event, stop_event);
+extern "C" int hivt_seg_attn_fwd_timed(const float* q, int64_t q_stride, const float* k, const float* v,
+                                       int64_t kv_stride, const float* k_node, const float* v_node,
+                                       int64_t node_stride, const int32_t* src, const int32_t* rowptr, int32_t N,
+                                       int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                                       const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                                       hivt_stream_t stream, void* start_event, void* stop_event) {
+  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H,
+                           dropout_p, seed, seed_ptr, out, m_out, den_out, dtype, stream, start_event, stop_event);
 }
 
-static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+static int seg_attn_bwd_impl(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                              const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                              const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
                              int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                             const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
-                             int32_t zero_tail, int dtype, hivt_stream_t stream, void* ev_start, void* ev_stop) {
+                             const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
+                             int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream, void* ev_start,
+                             void* ev_stop) {
   const char* what = "hivt_seg_attn_bwd";
   HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
@@ -666,8 +670,11 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
                what);
   HIVT_REQUIRE(!global || (v_node && src && node_stride >= D && node_stride % 4 == 0), HIVT_ERR_ARG,
                "%s: node terms need v_node, src and a 16-B aligned node_stride >= D", what);
+  HIVT_REQUIRE(q_stride >= D && q_stride % 4 == 0 && dq_stride >= D && dq_stride % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(dq)) & 15) == 0,
+               HIVT_ERR_ARG, "%s: q_stride / dq_stride must be >= D and the rows 16-B aligned", what);
   SegAttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.kv_stride = kv_stride;
+  a.q = q; a.q_stride = q_stride; a.dq_stride = dq_stride; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
   a.rowptr = rowptr; a.N = N; a.H = H;
   if (dtype & HIVT_ROWS_INTERLEAVED) {
@@ -695,26 +702,26 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, const float* k,
   return HIVT_OK;
 }
 
-extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v,
+extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v,
                                  int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
                                  const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
                                  const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, const uint64_t* seed_ptr, float* dq, float* dk, float* dv,
-                                 int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream) {
-  return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
-                           H, dropout_p, seed, seed_ptr, dq, dk, dv, dkv_stride, zero_tail, dtype, stream, nullptr,
-                           nullptr);
+                                 uint64_t seed, const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk,
+                                 float* dv, int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream) {
+  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den,
+                           N, E, D, H, dropout_p, seed, seed_ptr, dq, dq_stride, dk, dv, dkv_stride, zero_tail, dtype,
+                           stream, nullptr, nullptr);
 }
 
-extern "C" int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v,
-                                       int64_t kv_stride, const float* k_node, const float* v_node,
+extern "C" int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, int64_t q_stride, const float* k,
+                                       const float* v, int64_t kv_stride, const float* k_node, const float* v_node,
                                        int64_t node_stride, const int32_t* src, const int32_t* rowptr,
                                        const float* out, const float* m, const float* den, int32_t N, int64_t E,
                                        int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                                       const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
-                                       int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event,
-                                       void* stop_event) {
-  return seg_attn_bwd_impl(d_out, q, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den, N, E, D,
-                           H, dropout_p, seed, seed_ptr, dq, dk, dv, dkv_stride, zero_tail, dtype, stream,
-                           start_event, stop_event);
+                                       const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
+                                       int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream,
+                                       void* start_event, void* stop_event) {
+  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den,
+                           N, E, D, H, dropout_p, seed, seed_ptr, dq, dq_stride, dk, dv, dkv_stride, zero_tail, dtype,
+                           stream, start_event, stop_event);
 }

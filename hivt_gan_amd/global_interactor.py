@@ -44,8 +44,9 @@ class GlobalInteractorLayer(nn.Module):
                                  nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
 
     def paired_layers(self):
-        """Layer pairs evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
-        return [(self.lin_k_node, self.lin_v_node), (self.lin_k_edge, self.lin_v_edge), (self.lin_hh, self.lin_self)]
+        """Layers evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
+        return [(self.lin_q_node, self.lin_k_node, self.lin_v_node, self.lin_hh, self.lin_self),
+                (self.lin_k_edge, self.lin_v_edge)]
 
     def forward(self, x: torch.Tensor, edge_index: Optional[torch.Tensor], edge_attr: torch.Tensor, size=None,
                 edges: Optional[EdgeSet] = None) -> torch.Tensor:
@@ -62,6 +63,13 @@ class GlobalInteractorLayer(nn.Module):
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor,
                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         edges.group_by_source()
+        if ops.attention_block_supported(x, edge_attr, residual) and edges.src.dtype == torch.int32:
+            return ops.attention_block(x, residual, edge_attr, edges.rowptr, self.lin_q_node, self.lin_k_edge,
+                                       self.lin_v_edge, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
+                                       self.num_heads, self.attn_drop.p, self.proj_drop.p, self.training,
+                                       tag=type(self).__name__, padded=edges.count is not None,
+                                       lin_k_node=self.lin_k_node, lin_v_node=self.lin_v_node, src=edges.src,
+                                       rowptr_by_src=edges.rowptr_by_src, perm_by_src=edges.perm_by_src)
         q = _linear(x, self.lin_q_node)
         kv_node = _fused_linear(x, self.lin_k_node, self.lin_v_node)
         if edge_attr.is_cuda and edge_attr.dtype == torch.float32 and edges.src.dtype == torch.int32:

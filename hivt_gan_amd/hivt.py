@@ -86,19 +86,18 @@ class HiVT(nn.Module):
         return {"short": self.D_short, "mid": self.D_mid, "long": self.D_long}
 
     def pack_parameters(self) -> int:
-        """Lays the parameters of layer pairs that are evaluated as one product (K | V projections, the
-        two centre-row projections of the gated update) back to back in memory, so the step hands them
-        to the kernels without concatenating them first.  Values, names and ``state_dict`` are unchanged.
-        Call it with the model on its final device and before building optimizers; returns the number of
-        pairs packed."""
-        pairs = 0
+        """Lays the parameters of layers that are evaluated as one product (K | V projections, the projections
+        of an attention block's centre rows) back to back in memory, so the step hands them to the kernels
+        without concatenating them first.  Values, names and ``state_dict`` are unchanged.  Call it with the
+        model on its final device and before building optimizers; returns the number of groups packed."""
+        groups = 0
         for module in self.modules():
             if hasattr(module, "paired_layers"):
-                for a, b in module.paired_layers():
-                    ops.pack_rows([a.weight, b.weight])
-                    ops.pack_rows([a.bias, b.bias])
-                    pairs += 1
-        return pairs
+                for layers in module.paired_layers():
+                    ops.pack_rows([layer.weight for layer in layers])
+                    ops.pack_rows([layer.bias for layer in layers])
+                    groups += 1
+        return groups
 
     def generator_parameters(self) -> List[nn.Parameter]:
         """Parameter order of the generator optimizer (``models/hivt.py:439-442``)."""

@@ -225,8 +225,8 @@ class _EdgeAttentionBase(nn.Module):
                                  nn.Linear(embed_dim * 4, embed_dim), nn.Dropout(dropout))
 
     def paired_layers(self):
-        """Layer pairs evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
-        return [(self.lin_k, self.lin_v), (self.lin_hh, self.lin_self)]
+        """Layers evaluated as one product (``HiVT.pack_parameters`` lays their parameters back to back)."""
+        return [(self.lin_q, self.lin_hh, self.lin_self), (self.lin_k, self.lin_v)]
 
     def _attend_and_update(self, center: torch.Tensor, edge_embed: torch.Tensor, edges: EdgeSet,
                            residual: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None
@@ -234,9 +234,14 @@ class _EdgeAttentionBase(nn.Module):
         """``[residual +]`` message (Q.K, segment softmax, weighting) + aggregate + update + out_proj +
         dropout for per-edge embeddings already in CSR order (``local_encoder.py:174-188,197-199`` /
         ``:364-379,391-394``)."""
-        q = _linear(center, self.lin_q)
         # `rowptr`: the edge set's row pointer re-indexed to packed target rows (`center` then holds those rows)
         rowptr = edges.rowptr if rowptr is None else rowptr
+        if ops.attention_block_supported(center, edge_embed, residual):
+            return ops.attention_block(center, residual, edge_embed, rowptr, self.lin_q, self.lin_k, self.lin_v,
+                                       self.lin_ih, self.lin_hh, self.lin_self, self.out_proj, self.num_heads,
+                                       self.attn_drop.p, self.proj_drop.p, self.training, tag=type(self).__name__,
+                                       padded=edges.count is not None)
+        q = _linear(center, self.lin_q)
         if edge_embed.is_cuda and edge_embed.dtype == torch.float32 and edge_embed.dim() == 2:
             # key | value projection and attention as one node: their shared gradient stays inside it
             agg = ops.edge_attention(q, edge_embed, self.lin_k, self.lin_v, rowptr, self.num_heads, self.attn_drop.p,

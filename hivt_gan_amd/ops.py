@@ -51,6 +51,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+def _ld(t: torch.Tensor) -> int:
+    """Row stride of a 2-D tensor as a kernel wants it (a single row reports its width)."""
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
 def _rows(t: torch.Tensor) -> torch.Tensor:
     """A 2-D float32 view whose last dimension is contiguous (row stride arbitrary)."""
     if t.dtype != torch.float32:
@@ -372,7 +377,7 @@ class _SegAttn(torch.autograd.Function):
             raise ValueError(f"kv must be [E, 2*D] (K | V), got {tuple(kv.shape)} for D={d_model}")
         if rowptr.shape[0] != n + 1:
             raise ValueError("rowptr must have num_targets + 1 entries")
-        q = q.contiguous()
+        q = _rows(q)  # (may be a column block of a wider product: its row stride goes to the kernel)
         kv = _rows(kv)
         if kv_node is not None:
             kv_node = _rows(kv_node)
@@ -383,7 +388,7 @@ class _SegAttn(torch.autograd.Function):
         den = torch.empty(n, num_heads, dtype=torch.float32, device=q.device)
         fb = 4 * d_model
         _timed_call("fwd", tag, n, rowptr, d_model, num_heads, kv_node is not None, q.device,
-                    "hivt_seg_attn_fwd", _p(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
+                    "hivt_seg_attn_fwd", _p(q), _ld(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
                     _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(out),
@@ -401,8 +406,11 @@ class _SegAttn(torch.autograd.Function):
         n, d_model = q.shape
         e = kv.shape[0]
         d_out = d_out.contiguous()
-        dq = torch.empty_like(q)
-        # (set by a caller that consumes the key | value gradient itself, see _EdgeAttention)
+        # (set by a caller that runs this node's two halves itself, see _EdgeAttention / _AttentionBlock: where the
+        # query gradient goes, and whether that caller consumes the key | value gradient as bfloat16)
+        dq = getattr(ctx, "dq_out", None)
+        if dq is None:
+            dq = torch.empty(n, d_model, dtype=torch.float32, device=q.device)
         half = bool(getattr(ctx, "dkv_half", False))
         if half and (kv_node is not None or interleaved):
             raise RuntimeError("bfloat16 key | value gradients: plain rows only")
@@ -411,12 +419,12 @@ class _SegAttn(torch.autograd.Function):
         fb = 2 * d_model if half else 4 * d_model
         layout = (ROWS_INTERLEAVED if interleaved else 0) | (DKV_BF16 if half else 0)
         _timed_call("bwd", tag, n, rowptr, d_model, num_heads, kv_node is not None, q.device,
-                    "hivt_seg_attn_bwd", _p(d_out), _p(q), _p(kv), _p(kv, fb_kv),
+                    "hivt_seg_attn_bwd", _p(d_out), _p(q), _ld(q), _p(kv), _p(kv, fb_kv),
                     kv.stride(0) if e > 0 else 2 * d_model,
                     _p(kv_node), _p(kv_node, fb_kv) if kv_node is not None else None,
                     kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
                     _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
-                    _p(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, layout, _stream(q),
+                    _p(dq), _ld(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, layout, _stream(q),
                     grad_bytes=2 if half else 4)
         dkv_node = None
         if kv_node is not None and ctx.needs_input_grad[2]:
@@ -964,6 +972,19 @@ def _stacked(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return torch.cat([a, b], dim=0)
 
 
+def _stacked_all(tensors) -> torch.Tensor:
+    """``[t0; t1; ...]`` along dim 0 under the rules of ``_stacked``: a view when the tensors lie back to back."""
+    tensors = [t.detach() for t in tensors]
+    first = tensors[0]
+    at = first.storage_offset()
+    for t in tensors:
+        if not (t.is_contiguous() and t.shape[1:] == first.shape[1:] and t.dtype == first.dtype
+                and t.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and t.storage_offset() == at):
+            return torch.cat(tensors, dim=0)
+        at += t.numel()
+    return torch.as_strided(first, (sum(t.shape[0] for t in tensors),) + tuple(first.shape[1:]), first.stride())
+
+
 class _PairLinear(torch.autograd.Function):
     """``[x w_a^T + b_a | x w_b^T + b_b]``: one forward product, one data-gradient product and one
     weight-gradient product for two layers that read the same rows."""
@@ -1025,9 +1046,11 @@ class _PairLinear(torch.autograd.Function):
         if table_rows and ctx.needs_input_grad[5]:
             # every table row receives the sum of the gradient rows that picked it, in the fixed order of the
             # grouping by index (no atomics)
-            d_table = torch.empty(table_rows, n, dtype=torch.float32, device=dev)
+            d_table = getattr(ctx, "d_table_out", None)  # (a caller that runs this node itself may say where it goes)
+            if d_table is None:
+                d_table = torch.empty(table_rows, n, dtype=torch.float32, device=dev)
             _lib.call("hivt_segment_sum_rows", _p(dy2), dy2.stride(0), n, _p(rowptr_by_index), _p(perm_by_index),
-                      table_rows, _p(d_table), n, s)
+                      table_rows, _p(d_table), _ld(d_table), s)
         return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:], d_table, None, None, None
 
 
@@ -2226,6 +2249,172 @@ def gated_update_tail(agg: torch.Tensor, center: torch.Tensor, residual: torch.T
     return _GatedUpdateTail.apply(agg, center, residual, lin_ih.weight, lin_ih.bias, lin_hh.weight, lin_hh.bias,
                                   lin_self.weight, lin_self.bias, out_proj.weight, out_proj.bias, p,
                                   _fresh_seed() if p > 0.0 else 0)
+
+
+# --------------------------------------------------------------------------------------------
+# A whole edge-attention block as ONE autograd node
+# --------------------------------------------------------------------------------------------
+class _AttentionBlock(torch.autograd.Function):
+    """``res + drop(out_proj(agg + sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg)))`` with
+    ``agg = seg_attn(lin_q(c), [lin_k | lin_v](edge rows) [+ [lin_k_node | lin_v_node](c)[src]], rowptr)``
+    (``models/local_encoder.py:166-199, 356-394``; ``models/global_interactor.py:107-140``).
+
+    Every projection of the centre rows ``c`` -- query, (key | value node terms,) hh, self -- is a column block of ONE
+    product ``c [w_q; (w_k_node; w_v_node;) w_hh; w_self]^T`` whose blocks the attention and gate kernels read in
+    place through their row strides; backward fills ONE gradient ``dA`` of that product block by block (the
+    attention kernel writes dq, the per-source sums of dK | dV the node terms, the gate its two blocks) and takes the
+    centre rows' gradient and the stacked weights' gradient from it in one product each.  Against separate nodes
+    per projection that is two (four) launches fewer per pass and no summation of ``c``'s gradient routes.
+    Forward values equal the separate nodes' bit for bit; the centre rows' gradient is one reduction over all
+    blocks instead of a sum of rounded partial products."""
+
+    @staticmethod
+    def forward(ctx, center, res, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params):
+        num_heads, p_attn, seed_attn, p_out, seed_out, tag, padded, node_terms = cfg
+        if node_terms:
+            (w_q, b_q, w_kn, b_kn, w_vn, b_vn, w_hh, b_hh, w_self, b_self, w_k, b_k, w_v, b_v, w_ih, b_ih, w_out,
+             b_out) = params
+            centre_w, centre_b = [w_q, w_kn, w_vn, w_hh, w_self], [b_q, b_kn, b_vn, b_hh, b_self]
+        else:
+            w_q, b_q, w_hh, b_hh, w_self, b_self, w_k, b_k, w_v, b_v, w_ih, b_ih, w_out, b_out = params
+            centre_w, centre_b = [w_q, w_hh, w_self], [b_q, b_hh, b_self]
+        _need_gpu(center, res, edge_rows, w_q, w_out)
+        if center.dim() != 2 or edge_rows.dim() != 2:
+            raise ValueError("attention_block: centre rows [N, D] and edge rows [E, K]")
+        n, d = center.shape
+        dev, st = center.device, _stream(center)
+        c2, r2 = _rows2(center), _rows2(res)
+        wc, bc = _stacked_all(centre_w), _stacked_all(centre_b)
+        nc = wc.shape[0]
+        w_ih_c, w_out_c, b_ih_c, b_out_c = _rows2(w_ih), _rows2(w_out), b_ih.contiguous(), b_out.contiguous()
+
+        def linear(x, w, b, rows_out, out, drop=0.0, seed=0, residual=None):
+            _lib.call("hivt_linear_fwd", _p(x), _ld(x), _p(w), w.stride(0), _p(b), None, 0, None, 0, None, None, 0.0,
+                      EPI_NONE, 1.0, float(drop), int(seed), _seed_ptr(drop), _p(residual),
+                      _ld(residual) if residual is not None else 0, n, rows_out, d, _p(out), rows_out, None, 0, None, st)
+
+        a = torch.empty(n, nc, dtype=torch.float32, device=dev)
+        linear(c2, wc, bc, nc, a)
+        q, hs = a[:, :d], a[:, nc - 2 * d:]
+        proj, attn = _StandInContext(), _StandInContext()
+        if node_terms:
+            kv = _PairLinear.forward(proj, edge_rows, w_k, b_k, w_v, b_v, a[:, d:3 * d], src, rowptr_by_src, perm_by_src)
+        else:
+            kv = _PairLinear.forward(proj, edge_rows, w_k, b_k, w_v, b_v)
+        agg = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, p_attn, seed_attn, tag, padded)
+        ih = torch.empty(n, d, dtype=torch.float32, device=dev)
+        upd = torch.empty(n, d, dtype=torch.float32, device=dev)
+        y = torch.empty(n, d, dtype=torch.float32, device=dev)
+        linear(agg, w_ih_c, b_ih_c, d, ih)
+        _lib.call("hivt_gated_update_fwd", _p(agg), d, _p(ih), d, _p(hs), _ld(hs), _p(hs, 4 * d), _ld(hs), n, d, _p(upd), st)
+        linear(upd, w_out_c, b_out_c, d, y, p_out, seed_out, r2)
+        own = (c2, a, ih, upd, wc, w_ih_c, w_out_c, DEVICE_SEED if p_out > 0.0 else None)
+        ctx.save_for_backward(*own, *proj.saved_tensors, *attn.saved_tensors)
+        ctx.split = (len(own), len(own) + len(proj.saved_tensors))
+        ctx.stages = (proj.cfg, attn.cfg)
+        ctx.cfg = (float(p_out), int(seed_out), tuple(res.shape), bool(node_terms))
+        ctx.param_leaves = _all_leaves(*params)
+        ctx.res_leaf = res.is_leaf
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        c2, a, ih, upd, wc, w_ih, w_out, seed_dev = saved[:ctx.split[0]]
+        proj_cfg, attn_cfg = ctx.stages
+        p_out, seed_out, res_shape, node_terms = ctx.cfg
+        need = ctx.needs_input_grad
+        n, d = c2.shape
+        nc = wc.shape[0]
+        dev, st = c2.device, _stream(c2)
+        leaves = ctx.param_leaves
+        dy2 = _rows2(dy)
+        if p_out > 0.0:
+            dz = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_dropout_bwd", _p(dy2), _ld(dy2), None, 0, 0, p_out, seed_out, _p(seed_dev), n, d, _p(dz), d, st)
+        else:
+            dz = dy2
+
+        def wgrad(g, x, rows_out):
+            return _weight_grad(g, _ld(g), x, _ld(x), n, rows_out, d, dev, leaves=leaves)
+
+        def data_grad(g, w, rows_out, add=None):
+            dx = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_bwd_data", _p(g), _ld(g), _p(w), w.stride(0), n, rows_out, d, None, 0, 1.0, _p(add),
+                      d if add is not None else 0, _p(dx), d, st)
+            return dx
+
+        attn = _StandInContext((True, True) + (False,) * 11)
+        attn.saved_tensors, attn.cfg = saved[ctx.split[1]:], attn_cfg
+        agg = attn.saved_tensors[7]  # the attention's output (see _SegAttn.forward)
+        hs = a[:, nc - 2 * d:]
+        dw_out, db_out = wgrad(dz, upd, d)
+        d_upd = data_grad(dz, w_out, d)
+        da = torch.empty(n, nc, dtype=torch.float32, device=dev)
+        d_hs = da[:, nc - 2 * d:]
+        d_agg_direct = torch.empty(n, d, dtype=torch.float32, device=dev)
+        d_ih = torch.empty(n, d, dtype=torch.float32, device=dev)
+        _lib.call("hivt_gated_update_bwd", _p(d_upd), _p(agg), d, _p(ih), d, _p(hs), _ld(hs), _p(hs, 4 * d), _ld(hs), n, d,
+                  _p(d_agg_direct), _p(d_ih), _p(d_hs), _ld(d_hs), _p(d_hs, 4 * d), _ld(d_hs), st)
+        dw_ih, db_ih = wgrad(d_ih, agg, d)
+        d_agg = data_grad(d_ih, w_ih, d, add=d_agg_direct)  # both routes into the aggregated messages
+
+        proj = _StandInContext((need[2],) + (True,) * 4 + (node_terms,) + (False,) * 3)
+        proj.saved_tensors, proj.cfg, proj.param_leaves = saved[ctx.split[0]:ctx.split[1]], proj_cfg, leaves
+        x2, w_kv = proj.saved_tensors[0], proj.saved_tensors[1]
+        attn.dq_out = da[:, :d]
+        attn.dkv_half = (not node_terms and _half_gradients() and x2.shape[1] % 4 == 0 and w_kv.shape[0] % 8 == 0
+                         and x2.stride(0) % 4 == 0 and w_kv.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
+                         and w_kv.data_ptr() % 16 == 0)
+        dkv = _SegAttn.backward(attn, d_agg)[1]
+        if node_terms:
+            proj.d_table_out = da[:, d:3 * d]
+        d_edge, dw_k, db_k, dw_v, db_v = _PairLinear.backward(proj, dkv)[:5]
+
+        dwc, dbc = wgrad(da, c2, nc)
+        d_center = None
+        if need[0]:
+            d_center = torch.empty(n, d, dtype=torch.float32, device=dev)
+            _lib.call("hivt_linear_bwd_data", _p(da), _ld(da), _p(wc), wc.stride(0), n, nc, d, None, 0, 1.0, None, 0,
+                      _p(d_center), d, st)
+        blocks_w = [dwc[i * d:(i + 1) * d] for i in range(nc // d)]
+        blocks_b = [dbc[i * d:(i + 1) * d] for i in range(nc // d)]
+        centre = [g for pair in zip(blocks_w, blocks_b) for g in pair]
+        return (d_center, _pass_through_grad(dy, res_shape, ctx.res_leaf), d_edge, None, None, None, None, None,
+                *centre, dw_k, db_k, dw_v, db_v, dw_ih, db_ih, dw_out, db_out)
+
+
+def attention_block_supported(center: torch.Tensor, edge_rows: torch.Tensor, residual: Optional[torch.Tensor]) -> bool:
+    """Whether ``attention_block`` takes these operands (GPU float32, 2-D, a residual, a width the kernels stack)."""
+    return (residual is not None and center.is_cuda and center.dtype == torch.float32 and center.dim() == 2
+            and edge_rows.is_cuda and edge_rows.dtype == torch.float32 and edge_rows.dim() == 2
+            and center.shape[1] % 4 == 0)
+
+
+def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: torch.Tensor, rowptr: torch.Tensor,
+                    lin_q, lin_k, lin_v, lin_ih, lin_hh, lin_self, out_proj, num_heads: int, p_attn: float, p_out: float,
+                    training: bool, tag: str = "", padded: bool = False, lin_k_node=None, lin_v_node=None,
+                    src: Optional[torch.Tensor] = None, rowptr_by_src: Optional[torch.Tensor] = None,
+                    perm_by_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One edge-attention block -- query / key / value projections, segment-softmax attention over the CSR rows,
+    gate, update, output projection, dropout and residual -- as one autograd node.  ``center`` [N, D]: the
+    normalised target rows; ``edge_rows`` [E, K]: the per-edge embeddings in CSR order; ``residual`` [N, D].  With
+    ``lin_k_node`` / ``lin_v_node`` (the interaction module) an edge's key | value also receive the node terms of its
+    source ``src[e]`` (int32, CSR order; the CSR over sources gives their gradient), and sources are the centre rows."""
+    pa = float(p_attn) if training else 0.0
+    po = float(p_out) if training else 0.0
+    node_terms = lin_k_node is not None
+    if node_terms and (src is None or src.dtype != torch.int32 or rowptr_by_src is None or perm_by_src is None):
+        raise ValueError("attention_block: node terms need int32 source ids and the CSR over sources")
+    params = [lin_q.weight, lin_q.bias]
+    if node_terms:
+        params += [lin_k_node.weight, lin_k_node.bias, lin_v_node.weight, lin_v_node.bias]
+    params += [lin_hh.weight, lin_hh.bias, lin_self.weight, lin_self.bias, lin_k.weight, lin_k.bias, lin_v.weight,
+               lin_v.bias, lin_ih.weight, lin_ih.bias, out_proj.weight, out_proj.bias]
+    cfg = (int(num_heads), pa, _fresh_seed() if pa > 0.0 else 0, po, _fresh_seed() if po > 0.0 else 0, tag,
+           bool(padded), node_terms)
+    return _AttentionBlock.apply(center, residual, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params)
 
 
 # --------------------------------------------------------------------------------------------

@@ -276,44 +276,47 @@ int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angl
  * exp(s - max) / (sum + 1e-16) per (row, head) exactly as torch_geometric.utils.softmax; rows
  * without edges give zeros.  Replaces message()+aggregate of the three modules
  * (models/local_encoder.py:174-181, 364-371 and :98, :292; models/global_interactor.py:115-124, :75).
- * k / v rows are in CSR order with element stride kv_stride (so a fused [E,2D] K|V buffer works).
+ * k / v rows are in CSR order with element stride kv_stride (so a fused [E,2D] K|V buffer works); the
+ * query rows have element stride q_stride (>= D, a multiple of 4: the queries may be a column block of a wider
+ * product that also holds other projections of the same rows).
  * Saves the per-(row,head) max `m_out` and denominator `den_out` (float [N,H]) for backward.
  * Dropout (p > 0) uses a counter-based generator keyed on (seed + *seed_ptr, CSR position, head);
  * seed_ptr (device uint64, may be NULL) lets a captured graph draw fresh masks on every replay.
  * E is the number of k / v rows (a fixed capacity is fine: rows beyond rowptr[N] are never read). */
-int hivt_seg_attn_fwd(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+int hivt_seg_attn_fwd(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                       const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
                       int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
                       const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
                       hivt_stream_t stream);
 
-/* Backward of hivt_seg_attn_fwd: dq float [N,D]; dk / dv float rows in CSR order with element
+/* Backward of hivt_seg_attn_fwd: dq float [N,D] with element stride dq_stride; dk / dv float rows in CSR order with element
  * stride dkv_stride (gradient of the per-edge key/value, i.e. also of k_node[src[e]] before it is
  * summed per source -- use hivt_segment_sum_rows over a CSR-by-source for that).  The max is
  * treated as a constant, as torch_geometric detaches it.  With zero_tail != 0 the rows
  * [rowptr[N], E) of dk / dv (padding of a fixed-capacity list) are set to zero. */
-int hivt_seg_attn_bwd(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                       const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                       const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
                       int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
-                      float* dq, float* dk, float* dv, int64_t dkv_stride, int32_t zero_tail, int dtype,
-                      hivt_stream_t stream);
+                      float* dq, int64_t dq_stride, float* dk, float* dv, int64_t dkv_stride, int32_t zero_tail,
+                      int dtype, hivt_stream_t stream);
 
 /* hivt_seg_attn_fwd / _bwd with in-application timing: identical computation; additionally the
  * launch records the kernel's own start and stop time stamps into the two hipEvent_t handles
  * (created by the caller with timing enabled), so a step can price this kernel without the
  * dispatch gaps that events recorded around a launch include.  No counterpart in the reference. */
-int hivt_seg_attn_fwd_timed(const float* q, const float* k, const float* v, int64_t kv_stride, const float* k_node,
+int hivt_seg_attn_fwd_timed(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                             const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
                             int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
                             const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
                             hivt_stream_t stream, void* start_event, void* stop_event);
-int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, const float* k, const float* v, int64_t kv_stride,
+int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                             const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
                             const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
                             int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                            const uint64_t* seed_ptr, float* dq, float* dk, float* dv, int64_t dkv_stride,
-                            int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event, void* stop_event);
+                            const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
+                            int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event,
+                            void* stop_event);
 
 /* out[r, 0:width] = sum_{i in rowptr[r]..rowptr[r+1]} rows[perm[i], 0:width] in ascending i
  * (deterministic scatter-add without atomics; perm == NULL reads rows[i]).  Used for the

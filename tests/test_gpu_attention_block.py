@@ -1,0 +1,97 @@
+"""The edge-attention block as one autograd node against the same block built from separate nodes (query projection,
+key | value projection + attention, gated tail): forward bit for bit, gradients to rounding."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(d, node_terms, dev):
+    torch.manual_seed(11)
+    names = ["q", "k", "v", "ih", "hh", "self", "out"] + (["k_node", "v_node"] if node_terms else [])
+    return {n: torch.nn.Linear(d, d).to(dev) for n in names}
+
+
+def _csr(n, e, dev, gen):
+    dst = torch.sort(torch.randint(0, n, (e,), generator=gen)).values
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.bincount(dst, minlength=n).cumsum(0)
+    return rowptr.to(torch.int32).to(dev)
+
+
+@pytest.mark.parametrize("node_terms", [False, True])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_attention_block_equals_its_separate_nodes(node_terms, precision):
+    from hivt_gan_amd import ops
+    dev = torch.device("cuda", 0)
+    d, heads, n, e = 128, 8, 700, 9000
+    gen = torch.Generator().manual_seed(3)
+    lin = _modules(d, node_terms, dev)
+    rowptr = _csr(n, e, dev, gen)
+    src = torch.randint(0, n, (e,), generator=gen).to(torch.int32).to(dev)
+    order = torch.sort(src.long(), stable=True)
+    perm_by_src = order.indices.to(torch.int32)
+    rowptr_by_src = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr_by_src[1:] = torch.bincount(src.long(), minlength=n).cumsum(0)
+    rowptr_by_src = rowptr_by_src.to(torch.int32)
+    center0 = torch.randn(n, d, generator=gen).to(dev)
+    res0 = torch.randn(n, d, generator=gen).to(dev)
+    edge0 = torch.randn(e, d, generator=gen).to(dev)
+    weight = torch.randn(n, d, generator=gen).to(dev)
+    prev = ops.set_matmul_precision(precision)
+    try:
+        def run(fused):
+            for m in lin.values():
+                for p in m.parameters():
+                    p.grad = None
+            c, r, x = (t.clone().requires_grad_(True) for t in (center0, res0, edge0))
+            if fused:
+                y = ops.attention_block(c, r, x, rowptr, lin["q"], lin["k"], lin["v"], lin["ih"], lin["hh"], lin["self"],
+                                        lin["out"], heads, 0.0, 0.0, True, padded=False,
+                                        lin_k_node=lin.get("k_node"), lin_v_node=lin.get("v_node"),
+                                        src=src if node_terms else None,
+                                        rowptr_by_src=rowptr_by_src if node_terms else None,
+                                        perm_by_src=perm_by_src if node_terms else None)
+            else:
+                q = ops.fused_linear(c, lin["q"].weight, lin["q"].bias)
+                if node_terms:
+                    kv_node = ops.pair_linear(c, lin["k_node"], lin["v_node"])
+                    kv = ops.pair_linear(x, lin["k"], lin["v"], table=kv_node, index=src, rowptr_by_index=rowptr_by_src,
+                                         perm_by_index=perm_by_src)
+                    agg = ops.seg_attn(q, kv, rowptr, heads, 0.0, True)
+                else:
+                    agg = ops.edge_attention(q, x, lin["k"], lin["v"], rowptr, heads, 0.0, True)
+                y = ops.gated_update_tail(agg, c, r, lin["ih"], lin["hh"], lin["self"], lin["out"], 0.0, True)
+            (y * weight).sum().backward()
+            grads = {"center": c.grad, "res": r.grad, "edge": x.grad}
+            for name, m in lin.items():
+                grads[name + ".w"], grads[name + ".b"] = m.weight.grad.clone(), m.bias.grad.clone()
+            return y.detach(), grads
+
+        y_a, g_a = run(False)
+        y_b, g_b = run(True)
+    finally:
+        ops.set_matmul_precision(prev)
+    assert torch.equal(y_a, y_b)
+    # the centre rows' gradient is one reduction over all projections instead of a sum of rounded products
+    tol = 2e-6 if precision == "fp32" else 2e-3
+    for k in g_a:
+        err = float((g_a[k] - g_b[k]).norm() / g_a[k].norm().clamp_min(1e-30))
+        assert err <= (tol if k == "center" else 1e-6 if precision == "fp32" else tol), (k, err)
+
+
+def test_attention_block_dropout_and_padding_run_and_stay_finite():
+    from hivt_gan_amd import ops
+    dev = torch.device("cuda", 0)
+    d, heads, n, e = 128, 8, 300, 4000
+    gen = torch.Generator().manual_seed(5)
+    lin = _modules(d, False, dev)
+    rowptr = _csr(n, e - 500, dev, gen)  # 500 rows of padding behind the live edges
+    c = torch.randn(n, d, generator=gen).to(dev).requires_grad_(True)
+    r = torch.randn(n, d, generator=gen).to(dev).requires_grad_(True)
+    x = torch.randn(e, d, generator=gen).to(dev).requires_grad_(True)
+    y = ops.attention_block(c, r, x, rowptr, lin["q"], lin["k"], lin["v"], lin["ih"], lin["hh"], lin["self"], lin["out"],
+                            heads, 0.1, 0.1, True, padded=True)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(c.grad).all() and torch.isfinite(x.grad).all()
+    assert float(x.grad[e - 500:].abs().max()) == 0.0  # padded edge rows receive exact zeros

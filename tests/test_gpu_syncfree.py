@@ -305,7 +305,7 @@ def test_packed_parameters_change_nothing_but_the_copies():
     plain = hv.HiVT(**cfg).to("cuda:0")
     packed = hv.HiVT(**cfg).to("cuda:0")
     packed.load_state_dict(plain.state_dict())
-    assert packed.pack_parameters() == 2 * 2 + 2 * 3
+    assert packed.pack_parameters() == 2 * 2 + 2 * 2  # two groups per attention block: centre rows, edge rows
 
     def is_view(a, b):
         w = ops._stacked(a.weight, b.weight)
@@ -314,6 +314,9 @@ def test_packed_parameters_change_nothing_but_the_copies():
     layer = packed.global_interactor.global_interactor_layers[0]
     aa = packed.local_encoder.aa_encoder
     assert is_view(layer.lin_k_node, layer.lin_v_node) and is_view(layer.lin_hh, layer.lin_self)
+    stack = ops._stacked_all([m.weight for m in (layer.lin_q_node, layer.lin_k_node, layer.lin_v_node, layer.lin_hh,
+                                                  layer.lin_self)])
+    assert stack.data_ptr() == layer.lin_q_node.weight.data_ptr() and stack.shape == (5 * 64, 64)
     assert is_view(aa.lin_k, aa.lin_v)
     assert not is_view(plain.local_encoder.aa_encoder.lin_k, plain.local_encoder.aa_encoder.lin_v)
 

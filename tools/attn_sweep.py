@@ -76,17 +76,17 @@ def main():
         results = {"fwd": {}, "bwd": {}}
 
         def fwd(hint_bits, ev0, ev1, kv):
-            _lib.call("hivt_seg_attn_fwd_timed", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
+            _lib.call("hivt_seg_attn_fwd_timed", q.data_ptr(), D, kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
                       kv_node.data_ptr() if node_terms else None, kv_node.data_ptr() + fb if node_terms else None,
                       2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(), n, e, D,
                       H, 0.1, 1234, None, out.data_ptr(), m.data_ptr(), den.data_ptr(), hint_bits, stream.cuda_stream,
                       int(ev0.cuda_event), int(ev1.cuda_event))
 
         def bwd(hint_bits, ev0, ev1, kv):
-            _lib.call("hivt_seg_attn_bwd_timed", d_out.data_ptr(), q.data_ptr(), kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
+            _lib.call("hivt_seg_attn_bwd_timed", d_out.data_ptr(), q.data_ptr(), D, kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
                       kv_node.data_ptr() if node_terms else None, kv_node.data_ptr() + fb if node_terms else None,
                       2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(),
-                      out.data_ptr(), m.data_ptr(), den.data_ptr(), n, e, D, H, 0.1, 1234, None, dq.data_ptr(),
+                      out.data_ptr(), m.data_ptr(), den.data_ptr(), n, e, D, H, 0.1, 1234, None, dq.data_ptr(), D,
                       dkv.data_ptr(), dkv.data_ptr() + gfb, 2 * D, 0, hint_bits | gflag, stream.cuda_stream,
                       int(ev0.cuda_event), int(ev1.cuda_event))
 
