@@ -388,6 +388,7 @@ struct ReduceEntry {
   int32_t term_chunks[kJoinMax];  // term_chunks[t] = 0: no such term
   int32_t accumulate;
   int32_t K, ld;    // columns of a weight-gradient row and the distance between rows in `out` (ld >= K)
+  int32_t vec;      // four columns per thread
 };
 
 struct ReduceGroup {
@@ -396,31 +397,75 @@ struct ReduceGroup {
   int32_t count;
 };
 
-__global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) {
-  int i = 0;
-  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
-  const ReduceEntry& e = g.e[i];
-  const int c = ((int)blockIdx.x - g.first_block[i]) * 256 + (int)threadIdx.x;
+// W columns per thread (4 where every term's rows allow 16-byte loads), four chunk rows requested at a time; a
+// column's sum keeps its association whatever W is.
+template <int W>
+__device__ __forceinline__ void reduce_entry_columns(const ReduceEntry& e, int c) {
   if (c >= e.cols) return;
-  float total = 0.0f;
+  typedef float vec_t __attribute__((ext_vector_type(W)));
+  float total[W];
 #pragma unroll
   for (int term = 0; term < kJoinMax; ++term) {
     const int R = e.term_chunks[term];
     if (R == 0) continue;
     const float* base = e.term_base[term] + c;
     const int per = (R + 3) / 4;
-    float t = 0.0f;
+    float t[W];
     for (int sl = 0; sl < 4; ++sl) {
       const int r0 = min(R, sl * per), r1 = min(R, r0 + per);
-      float s = 0.0f;
-      for (int r = r0; r < r1; ++r) s += base[(int64_t)r * e.pitch];
-      t = sl == 0 ? s : t + s;
+      float s[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) s[j] = 0.0f;
+      int r = r0;
+      for (; r + 4 <= r1; r += 4) {
+        vec_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec_t*>(base + (int64_t)(r + u) * e.pitch);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < W; ++j) s[j] += v[u][j];
+      }
+      for (; r < r1; ++r) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(base + (int64_t)r * e.pitch);
+#pragma unroll
+        for (int j = 0; j < W; ++j) s[j] += v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) t[j] = sl == 0 ? s[j] : t[j] + s[j];
     }
-    total = term == 0 ? t : total + t;
+#pragma unroll
+    for (int j = 0; j < W; ++j) total[j] = term == 0 ? t[j] : total[j] + t[j];
   }
   if (c >= e.split && e.out1 == nullptr) return;  // bias columns of an entry without a bias gradient
-  float* dst = c >= e.split ? e.out1 + (c - e.split) : (e.ld == e.K ? e.out + c : e.out + (int64_t)(c / e.K) * e.ld + c % e.K);
-  *dst = e.accumulate ? *dst + total : total;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int cj = c + j;  // (split is a multiple of W: the W columns lie on one side of it)
+    float* dst = cj >= e.split ? e.out1 + (cj - e.split)
+                               : (e.ld == e.K ? e.out + cj : e.out + (int64_t)(cj / e.K) * e.ld + cj % e.K);
+    *dst = e.accumulate ? *dst + total[j] : total[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_group_kernel(const ReduceGroup g) {
+  int i = 0;
+  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
+  const ReduceEntry& e = g.e[i];
+  const int slot = ((int)blockIdx.x - g.first_block[i]) * 256 + (int)threadIdx.x;
+  if (e.vec)
+    reduce_entry_columns<4>(e, slot * 4);
+  else
+    reduce_entry_columns<1>(e, slot);
+}
+
+// Blocks of an entry, after deciding whether its columns go four to a thread.
+inline int reduce_entry_blocks(ReduceEntry& e) {
+  bool vec = e.cols % 4 == 0 && e.split % 4 == 0 && e.pitch % 4 == 0;
+  for (int t = 0; t < kJoinMax; ++t)
+    if (e.term_chunks[t] != 0 && (reinterpret_cast<uintptr_t>(e.term_base[t]) & 15) != 0) vec = false;
+  e.vec = vec ? 1 : 0;
+  const int per_block = vec ? 1024 : 256;
+  return (e.cols + per_block - 1) / per_block;
 }
 
 // out[c] = sum_r partial[r * pitch + c], c < C.  Fixed association: SLICES row slices are summed
@@ -1013,7 +1058,7 @@ int reduce_column_sums_group(const ColumnSums* entries, int count, hipStream_t s
       e.cols = c.cols; e.split = c.split;
       e.accumulate = c.accumulate;
       e.K = c.split; e.ld = c.split;
-      g.first_block[i + 1] = g.first_block[i] + (c.cols + 255) / 256;
+      g.first_block[i + 1] = g.first_block[i] + reduce_entry_blocks(e);
     }
     hipLaunchKernelGGL(reduce_group_kernel, dim3((unsigned)g.first_block[n]), dim3(256), 0, stream, g);
   }
@@ -1508,8 +1553,8 @@ extern "C" int hivt_linear_wgrad_group(const int64_t* items, int32_t count, void
     e.cols = (int32_t)e.pitch; e.split = it.N * it.K;
     e.K = it.K; e.ld = it.wide_rows ? 2 * it.K : it.K;
     e.accumulate = it.accumulate ? 1 : 0;
+    rg.first_block[rg.count + 1] = rg.first_block[rg.count] + reduce_entry_blocks(e);
     rg.e[rg.count] = e;
-    rg.first_block[rg.count + 1] = rg.first_block[rg.count] + (e.cols + 255) / 256;
     if (++rg.count == kGroupMax) flush_sums();
   }
   flush_sums();

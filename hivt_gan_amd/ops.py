@@ -675,7 +675,8 @@ def _launch_wgrad_group(flat, count: int, dev) -> None:
 # feeding two nodes of a graph, ``retain_graph`` replays, ``create_graph=True`` -- is checked when the queue is
 # issued: every buffer must by then BE the ``.grad`` of one of its node's parameters, otherwise the pass raises
 # instead of training on a sum that contains an unfilled buffer.  Nothing may read a parameter's ``.grad`` from a
-# hook before the pass has ended.
+# hook before the pass has ended -- except a hook registered through ``trust_grad_hook``, which issues the queue
+# (``flush_weight_grads(final=False)``) before it reads (the data-parallel bucket's chunk-complete hook).
 _deferred: Optional[list] = None
 
 
@@ -694,6 +695,7 @@ class deferred_weight_grads:
             if exc[0] is None:
                 flush_weight_grads()
         finally:
+            del _pending_checks[:]
             _deferred, _deferred_rows = self._prev
         return False
 
@@ -712,10 +714,23 @@ def _check_adopted(entries) -> None:
                     "outside deferred_weight_grads() (GanTrainer.defer_weight_grads = False)")
 
 
-def flush_weight_grads() -> None:
-    """Issues the collected weight gradients (runs by itself at the end of every backward pass)."""
+_pending_checks: list = []   # adoption checks of products issued before the end of the pass (see flush_weight_grads)
+_trusted_hooks: set = set()  # grad-ready hooks that read no gradient before having flushed the queue
+
+
+def trust_grad_hook(hook) -> None:
+    """Declares a post-accumulate-grad hook safe for deferred weight gradients: it reads no ``.grad`` unless it has
+    called ``flush_weight_grads(final=False)`` first (the data-parallel bucket's chunk-complete hook does)."""
+    _trusted_hooks.add(hook)
+
+
+def flush_weight_grads(final: bool = True) -> None:
+    """Issues the collected weight gradients (runs by itself at the end of every backward pass).  ``final=False``:
+    called from inside the pass (a chunk of parameters is complete and about to be read): everything queued so far
+    is issued, and the check that every buffer became a ``.grad`` waits for the end of the pass, when the
+    accumulation nodes of the graph have all run."""
     rows = _deferred_rows
-    checks = []
+    checks = _pending_checks
     if rows:
         flat, keep, dev = [], [], rows[0][1]
         for item, _, part, check in rows:
@@ -738,7 +753,10 @@ def flush_weight_grads() -> None:
         del queue[:]
         _launch_wgrad_group(flat, count, dev)
         del keep  # the operands stayed alive until the call that reads them was issued
-    _check_adopted([c for c in checks if c is not None])
+    if final:
+        entries = [c for c in checks if c is not None]
+        del checks[:]
+        _check_adopted(entries)
 
 
 def _all_leaves(*tensors):
@@ -755,7 +773,10 @@ def _may_defer(leaves) -> bool:
     if not leaves or _deferred is None:
         return False
     for p in leaves:
-        if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+        if p.grad is not None or p._backward_hooks:
+            return False
+        ready_hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+        if ready_hooks and any(h not in _trusted_hooks for h in ready_hooks.values()):
             return False
     return True
 

@@ -99,6 +99,8 @@ class FlatGradBucket:
         self._armed = False
         self._hooks = []
         if self.overlap:
+            from . import ops
+            ops.trust_grad_hook(self._on_grad)  # (it issues the deferred weight gradients before it reads any)
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -135,6 +137,11 @@ class FlatGradBucket:
         while self._next >= 0 and (force or self._pending[self._next] == 0):
             i = self._next
             if not self._packed[i]:
+                if not force and self.flat.is_cuda:
+                    # weight gradients whose products wait for the end of the pass are adopted, not filled yet:
+                    # issue what is queued before the chunk is read
+                    from . import ops
+                    ops.flush_weight_grads(final=False)
                 self._pack_chunk(i)
             self._reduce(i, async_op=not force)
             self._next -= 1
@@ -366,11 +373,11 @@ class GanTrainer:
         return out
 
     def _weight_grad_scope(self):
-        """Small weight-gradient products of a backward pass are issued together at its end, unless grad-ready
-        hooks (overlapped data-parallel reduction) read gradients while the pass is still running."""
+        """Small weight-gradient products of a backward pass are issued together at its end; under the overlapped
+        data-parallel reduction, whose grad-ready hooks read gradients while the pass is still running, together
+        whenever a chunk of parameters is complete (``FlatGradBucket._launch_ready``)."""
         from . import ops
-        hooked = self.distributed and any(b.overlap for b in self.buckets.values())
-        if self.defer_weight_grads and not hooked and next(self.model.parameters()).is_cuda:
+        if self.defer_weight_grads and next(self.model.parameters()).is_cuda:
             return ops.deferred_weight_grads()
         return contextlib.nullcontext()
 

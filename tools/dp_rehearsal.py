@@ -2,8 +2,9 @@
 the real GPU model (RCCL needs one device per rank, so this rehearses everything but the transport).
 
 Each rank logs its stages to gpurun_out/dp_rank<r>.log and dumps its Python stack if it stalls.
-Checks: ranks hold identical parameters after every step, the losses are finite, and the first
-step's reduced generator gradient equals the mean of the two ranks' local gradients.
+Checks: ranks hold identical parameters after every step, the losses are finite, the first step's reduced
+generator gradient equals the mean of the two ranks' local gradients, and the step replayed from its recorded
+segments (reductions between them) leaves the same bits in the parameters as the eager step from the same state.
 """
 import faulthandler
 import os
@@ -43,12 +44,28 @@ def worker(rank, world, port, steps):
     cfg["dropout"] = 0.0
     model = hv.HiVT(**cfg).to(dev)
     model.train()
+    for critic in model.critics.values():  # no dropout anywhere: recorded and eager steps can be compared bit by bit
+        for mod in critic.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
     pool = [hv.make_batch(16, first_index=(rank * 4 + i) * 16).to(dev) for i in range(4)]
     ys = [b["y"] for b in pool]
     capacity = hv.GanTrainer.calibrate(model, pool).edge_capacity
     say("calibrated")
-    trainer = hv.GanTrainer(model, edge_capacity=capacity)
-    say("trainer built, distributed =", trainer.distributed)
+    # HIVT_REHEARSAL_OVERLAP=1: the chunked reductions that go out from grad-ready hooks during the backward pass
+    # (over gloo nothing overlaps, but every hook, chunk and deferred weight-gradient launch runs as under RCCL)
+    forced = os.environ.get("HIVT_REHEARSAL_OVERLAP") == "1"
+    trainer = hv.GanTrainer(model, edge_capacity=capacity, overlap=True if forced else None)
+    say("trainer built, distributed =", trainer.distributed, "overlap =", trainer.buckets["generator"].overlap)
+    from hivt_gan_amd import ops as _ops
+    grouped = {"launches": 0, "products": 0}
+    plain_group = _ops._launch_wgrad_group
+
+    def counting_group(flat, count, device):
+        grouped["launches"] += 1
+        grouped["products"] += count
+        return plain_group(flat, count, device)
+    _ops._launch_wgrad_group = counting_group
 
     def run_step(i):
         b = pool[i % len(pool)]
@@ -79,7 +96,7 @@ def worker(rank, world, port, steps):
         dist.all_gather(both, state)
         assert torch.equal(both[0], both[1]), f"ranks diverged after step {i}"
         assert all(bool(torch.isfinite(v).all()) for v in logs.values())
-        if i == 0:
+        if i == 0 and not forced:  # (under the hooks the chunks are already reduced when the wrapper first looks)
             for group in ("critic", "generator"):
                 mine = local[group] if backend == "nccl" else local[group].cpu()
                 parts = [torch.empty_like(mine) for _ in range(world)]
@@ -90,6 +107,9 @@ def worker(rank, world, port, steps):
                 say(group, "reduced vs mean of locals: err", err, "scale", scale)
                 assert scale > 0 and err <= 1e-6 * scale
     trainer._sync = plain_sync
+    say("grouped weight-gradient launches", grouped)
+    # weight gradients stay deferred and grouped under the hooks of the overlapped reduction too
+    assert grouped["products"] > 20 * steps and grouped["launches"] < grouped["products"] // 4, grouped
     tuned = trainer.tune(run_step)
     say("tuned", tuned)
     for i in range(3):
@@ -119,6 +139,24 @@ def worker(rank, world, port, steps):
         assert torch.equal(both[0], both[1]), f"ranks diverged after recorded step {i}"
         assert all(bool(torch.isfinite(v).all()) for v in logs.values())
         say("recorded step", i, round(float(logs["g_total"]), 5))
+    # a recorded step and the eager step from the same state leave the same bits in every parameter (no dropout in
+    # this configuration, so the two draw nothing differently)
+    def parameters_now():
+        return torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+
+    snapshot = recorded._snapshot()
+    recorded.run(padded[1])
+    torch.cuda.synchronize()
+    after_replay = parameters_now()
+    recorded._restore(snapshot)
+    eager = padded[1]
+    eager["edge_plan"] = None
+    trainer.step(eager)
+    torch.cuda.synchronize()
+    after_eager = parameters_now()
+    differing = int((after_replay != after_eager).sum())
+    say("recorded vs eager step: parameters that differ", differing, "of", after_eager.numel())
+    assert differing == 0, "the recorded data-parallel step and the eager one disagree"
     dist.barrier()
     say("OK")
     faulthandler.cancel_dump_traceback_later()
