@@ -41,6 +41,7 @@ SIGNATURES = {
     "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P,
                                         c_int32, c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, c_int64, _P,
                                         _P, c_int64, c_int32, c_int, _P, _P, _P]),
+    "hivt_stack_pairs": (c_int, [_P, c_int32, _P]),
     "hivt_segment_sum_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
     "hivt_gated_update_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P]),
     "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,

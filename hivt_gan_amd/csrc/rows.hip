@@ -638,6 +638,75 @@ extern "C" int hivt_sum_padded_rows(const float* const* parts, const int32_t* wi
   return HIVT_OK;
 }
 
+namespace hivt {
+namespace {
+// out[r] = [a[r] | b[r]] and bias_out = bias_a + bias_b for up to eight pairs of layers in one launch
+constexpr int kStackMax = 8;
+struct StackPair {
+  const float* a;
+  const float* b;
+  float* out;
+  const float* bias_a;
+  const float* bias_b;
+  float* bias_out;
+  int32_t rows, ka, kb;
+};
+struct StackArgs {
+  StackPair pair[kStackMax];
+  int32_t first_block[kStackMax + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void stack_pairs_kernel(const StackArgs g) {
+  int i = 0;
+  while (i + 1 < g.count && g.first_block[i + 1] <= (int)blockIdx.x) ++i;
+  const StackPair& p = g.pair[i];
+  const int width = p.ka + p.kb;
+  const int64_t total = (int64_t)p.rows * width;
+  const int blocks = g.first_block[i + 1] - g.first_block[i];
+  const int64_t start = (int64_t)((int)blockIdx.x - g.first_block[i]) * 256 + threadIdx.x;
+  for (int64_t e = start; e < total; e += (int64_t)blocks * 256) {
+    const int r = (int)(e / width), c = (int)(e % width);
+    p.out[e] = c < p.ka ? p.a[(int64_t)r * p.ka + c] : p.b[(int64_t)r * p.kb + (c - p.ka)];
+  }
+  if (p.bias_out != nullptr)
+    for (int64_t r = start; r < p.rows; r += (int64_t)blocks * 256) p.bias_out[r] = p.bias_a[r] + p.bias_b[r];
+}
+}  // namespace
+}  // namespace hivt
+
+extern "C" int hivt_stack_pairs(const int64_t* items, int32_t count, hivt_stream_t stream) {
+  const char* what = "hivt_stack_pairs";
+  HIVT_REQUIRE(count >= 0 && (count == 0 || items != nullptr), HIVT_ERR_ARG, "%s: bad arguments", what);
+  for (int32_t first = 0; first < count; first += kStackMax) {
+    StackArgs g{};
+    const int n = count - first < kStackMax ? count - first : kStackMax;
+    g.count = n;
+    for (int i = 0; i < n; ++i) {
+      const int64_t* t = items + (size_t)(first + i) * 9;
+      StackPair& p = g.pair[i];
+      p.a = reinterpret_cast<const float*>(t[0]);
+      p.b = reinterpret_cast<const float*>(t[1]);
+      p.out = reinterpret_cast<float*>(t[2]);
+      p.rows = (int32_t)t[3]; p.ka = (int32_t)t[4]; p.kb = (int32_t)t[5];
+      p.bias_a = reinterpret_cast<const float*>(t[6]);
+      p.bias_b = reinterpret_cast<const float*>(t[7]);
+      p.bias_out = reinterpret_cast<float*>(t[8]);
+      HIVT_REQUIRE(p.a && p.b && p.out && p.rows > 0 && p.ka > 0 && p.kb > 0, HIVT_ERR_ARG,
+                   "%s: item %d: null pointer or empty shape", what, first + i);
+      HIVT_REQUIRE((p.bias_out == nullptr) == (p.bias_a == nullptr) && (p.bias_a == nullptr) == (p.bias_b == nullptr),
+                   HIVT_ERR_ARG, "%s: item %d: the three bias pointers go together", what, first + i);
+      const int64_t total = (int64_t)p.rows * (p.ka + p.kb);
+      int64_t blocks = (total + 1023) / 1024;
+      if (blocks > 64) blocks = 64;
+      g.first_block[i + 1] = g.first_block[i] + (int32_t)blocks;
+    }
+    hipLaunchKernelGGL(stack_pairs_kernel, dim3((unsigned)g.first_block[n]), dim3(256), 0, (hipStream_t)stream, g);
+    HIVT_CHECK_LAUNCH(what);
+  }
+  return HIVT_OK;
+}
+
 extern "C" int hivt_category_table_fwd(const float* a, const float* b, const float* c, int32_t na, int32_t nb, int32_t nc,
                                        int32_t D, float* out, hivt_stream_t stream) {
   const char* what = "hivt_category_table_fwd";

@@ -107,8 +107,10 @@ class MultipleInputEmbedding(nn.Module):
         if len(self.module_list) == 2 and h.is_cuda:
             # (the two layers' own parameters go down: their gradients come back per layer, as leaves of the graph)
             first, second = self.module_list[0][3], self.module_list[1][3]
+            # (the weights side by side, if the model has laid them out for this pass already: used once)
+            stacked = self.__dict__.pop("_stacked_pair", None)
             h = ops.fused_linear(h, first.weight, first.bias, add=extra, layer_norm=a[0], relu=True, add_index=extra_index,
-                                 weight_b=second.weight, bias_b=second.bias)
+                                 weight_b=second.weight, bias_b=second.bias, stacked=stacked)
             return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
         weight = self.module_list[0][3].weight if len(self.module_list) == 1 else \
             torch.cat([br[3].weight for br in self.module_list], dim=1)
@@ -117,6 +119,14 @@ class MultipleInputEmbedding(nn.Module):
             bias = bias + br[3].bias
         h = ops.fused_linear(h, weight, bias, add=extra, layer_norm=a[0], relu=True, add_index=extra_index)
         return ops.fused_linear(h, a[2].weight, a[2].bias, layer_norm=a[3], relu=False)
+
+    def summed_pair(self):
+        """``(w_a, b_a, w_b, b_b)`` of the two branches' second Linears if the module has two branches whose outputs
+        are summed as one product, else None."""
+        if len(self.module_list) != 2:
+            return None
+        first, second = self.module_list[0][3], self.module_list[1][3]
+        return first.weight, first.bias, second.weight, second.bias
 
     def forward(self, continuous_inputs: List[torch.Tensor],
                 categorical_inputs: Optional[List[torch.Tensor]] = None) -> torch.Tensor:

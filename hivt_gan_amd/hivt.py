@@ -99,6 +99,18 @@ class HiVT(nn.Module):
                     groups += 1
         return groups
 
+    def _stack_embedding_pairs(self) -> list:
+        """The summed branch layers of the three edge embeddings (``models/embedding.py:49-52``) run as one product
+        each over the weights side by side: lays those out for this forward pass, all modules in one launch."""
+        if not next(self.parameters()).is_cuda:
+            return []
+        from .embedding import MultipleInputEmbedding
+        modules = [m for m in self.modules() if isinstance(m, MultipleInputEmbedding) and m.summed_pair() is not None
+                   and m.summed_pair()[0].dtype == torch.float32]
+        for m, stacked in zip(modules, ops.stack_pairs([m.summed_pair() for m in modules])):
+            m.__dict__["_stacked_pair"] = stacked
+        return modules
+
     def generator_parameters(self) -> List[nn.Parameter]:
         """Parameter order of the generator optimizer (``models/hivt.py:439-442``)."""
         return (list(self.local_encoder.parameters()) + list(self.global_interactor.parameters())
@@ -150,8 +162,13 @@ class HiVT(nn.Module):
             data["rotate_mat"] = rotate_mat
         else:
             data["rotate_mat"] = None
-        local_embed = self.local_encoder(data=data)
-        global_embed = self.global_interactor(data=data, local_embed=local_embed)
+        stacked_for = self._stack_embedding_pairs()
+        try:
+            local_embed = self.local_encoder(data=data)
+            global_embed = self.global_interactor(data=data, local_embed=local_embed)
+        finally:
+            for m in stacked_for:  # (a module that did not run keeps nothing for a later pass with other weights)
+                m.__dict__.pop("_stacked_pair", None)
         return self.decoder(local_embed=local_embed, global_embed=global_embed)
 
     def _supervised_losses(self, data, y_hat: torch.Tensor, pi: torch.Tensor):

@@ -842,7 +842,7 @@ class _FusedLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, add, gamma, beta, relu, eps, add_index, dropout_p, seed, residual,
-                weight_b=None, bias_b=None):
+                weight_b=None, bias_b=None, stacked=None):
         _need_gpu(x, weight)
         lead = x.shape[:-1]
         x2 = _rows2(x)
@@ -855,8 +855,13 @@ class _FusedLinear(torch.autograd.Function):
             if (bias is None) != (bias_b is None) or weight_b.shape[0] != n:
                 raise ValueError("the two layers of a pair have the same output width and both or neither a bias")
             ctx.pair = (int(weight.shape[1]), _all_leaves(weight, bias), _all_leaves(weight_b, bias_b))
-            weight = torch.cat([weight, weight_b], dim=1)
-            bias = bias + bias_b if bias is not None else None
+            if stacked is not None:  # ([weight | weight_b], bias + bias_b) made by stack_pairs for this pass
+                weight, bias = stacked
+                if weight.shape != (n, ctx.pair[0] + weight_b.shape[1]):
+                    raise ValueError("the stacked weight does not match the two layers")
+            else:
+                weight = torch.cat([weight, weight_b], dim=1)
+                bias = bias + bias_b if bias is not None else None
         if weight.shape[1] != k:
             raise ValueError(f"weight {tuple(weight.shape)} does not match input width {k}")
         w2 = _rows2(weight)
@@ -959,7 +964,7 @@ class _FusedLinear(torch.autograd.Function):
                           ws.numel(), s)
         dres = _pass_through_grad(dy, res_shape, ctx.res_leaf) \
             if (res_shape is not None and ctx.needs_input_grad[11]) else None
-        return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres, dw_b, db_b
+        return dx, dw, db, dadd, dgamma, dbeta, None, None, None, None, None, dres, dw_b, db_b, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -1300,13 +1305,15 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
                  add: Optional[torch.Tensor] = None, layer_norm: Optional[torch.nn.LayerNorm] = None,
                  relu: bool = False, add_index: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
                  training: bool = False, residual: Optional[torch.Tensor] = None,
-                 weight_b: Optional[torch.Tensor] = None, bias_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 weight_b: Optional[torch.Tensor] = None, bias_b: Optional[torch.Tensor] = None,
+                 stacked: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
     """``[residual +] [dropout]([relu]([layer_norm](x @ weight.T + bias [+ add])))`` in one launch (exact
     fp32 on the matrix cores).  With ``add_index`` (int32, one entry per row) ``add`` is a small table
     [codes <= 16, N] and row m adds ``add[add_index[m]]``.  Dropout (active when ``training``) and the
     residual are part of the plain epilogues only (no ``layer_norm``).  With ``weight_b`` / ``bias_b`` the product is
     ``x[:, :k0] @ weight.T + x[:, k0:] @ weight_b.T + bias + bias_b`` (two layers whose outputs are summed, as one
-    product over the weights side by side).
+    product over the weights side by side; ``stacked``: that matrix and the summed bias if ``stack_pairs`` has
+    made them already).
 
     CPU tensors are refused; a LayerNorm epilogue wider than 128 columns raises ``UnsupportedShapeError``."""
     _need_gpu(x, weight)
@@ -1318,7 +1325,33 @@ def fused_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     beta = layer_norm.bias if layer_norm is not None else None
     eps = layer_norm.eps if layer_norm is not None else 0.0
     return _FusedLinear.apply(x, weight, bias, add, gamma, beta, bool(relu), eps, add_index, p,
-                              _fresh_seed() if p > 0.0 else 0, residual, weight_b, bias_b)
+                              _fresh_seed() if p > 0.0 else 0, residual, weight_b, bias_b, stacked)
+
+
+def stack_pairs(pairs):
+    """``[(cat([w_a, w_b], dim=1), b_a + b_b), ...]`` for pairs ``(w_a, b_a, w_b, b_b)`` of float32 GPU layers with
+    the same number of rows: all pairs in ONE launch (no autograd history: the results are values for
+    ``fused_linear(..., stacked=)``, whose gradients go to the layers' own parameters)."""
+    out, flat, keep = [], [], []
+    for w_a, b_a, w_b, b_b in pairs:
+        _need_gpu(w_a, w_b)
+        w_a, w_b = w_a.detach().contiguous(), w_b.detach().contiguous()
+        if w_a.dim() != 2 or w_b.dim() != 2 or w_a.shape[0] != w_b.shape[0] or (b_a is None) != (b_b is None):
+            raise ValueError("stack_pairs: two [N, K] weights with the same N, both or neither with a bias")
+        n = w_a.shape[0]
+        w = torch.empty(n, w_a.shape[1] + w_b.shape[1], dtype=torch.float32, device=w_a.device)
+        b = None
+        if b_a is not None:
+            b_a, b_b = b_a.detach().contiguous(), b_b.detach().contiguous()
+            b = torch.empty(n, dtype=torch.float32, device=w_a.device)
+        flat += [w_a.data_ptr(), w_b.data_ptr(), w.data_ptr(), n, w_a.shape[1], w_b.shape[1],
+                 b_a.data_ptr() if b is not None else 0, b_b.data_ptr() if b is not None else 0,
+                 b.data_ptr() if b is not None else 0]
+        keep.append((w_a, w_b, b_a, b_b))
+        out.append((w, b))
+    if out:
+        _lib.call("hivt_stack_pairs", (ctypes.c_int64 * len(flat))(*flat), len(out), _stream(out[0][0]))
+    return out
 
 
 # --------------------------------------------------------------------------------------------

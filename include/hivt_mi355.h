@@ -180,6 +180,14 @@ int hivt_center_rows(const float* x_rot, const uint8_t* bos_mask, int64_t bos_st
 int hivt_rows_put_tokens(const float* x, int64_t x_ld, const int32_t* code, const float* token, int64_t M, int32_t D,
                          int32_t keep_coded, float* out, hivt_stream_t stream);
 
+/* For each of `count` pairs of layers: out[r] = [a[r] | b[r]] (rows of ka and kb floats side by side) and
+ * bias_out = bias_a + bias_b, all pairs in one launch.  The second Linear of the two branches of a
+ * MultipleInputEmbedding are summed (models/embedding.py:49-52): the sum is one product of the concatenated
+ * hidden rows with the weights side by side, and this call lays them side by side once per forward pass.
+ * items: 9 x int64 per pair = { a, b, out, rows, ka, kb, bias_a, bias_b, bias_out } (pointers as integers; the
+ * three bias pointers all null or all set). */
+int hivt_stack_pairs(const int64_t* items, int32_t count, hivt_stream_t stream);
+
 /* Input of the temporal encoder (models/local_encoder.py:230-232): for s < T
  *   out[s, n] = (padding_mask[n][s] ? padding_token[s] : x[new_id[s*N + n]]) + pos_embed[s]
  * and out[T, n] = cls_token + pos_embed[T].  new_id == NULL: x holds all T*N rows.  pad_code[(T+1)*N] receives s
