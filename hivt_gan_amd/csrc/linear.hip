@@ -239,6 +239,7 @@ struct BwdDataArgs {
   const float* add;   // optional [M,K], exclusive with mask: dx += add
   int64_t add_ld;
   int32_t dx_half;    // dx is stored as bfloat16
+  int32_t mask_bits;  // mask points at one bit per element (32-bit words, mask_ld words per row), set = mask > 0
 };
 
 // HY: dy holds bfloat16 values in memory
@@ -252,7 +253,11 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_data_kernel(const BwdData
   f32x16 acc0, acc1;
   C::accumulate(a.dy, a.w, row0, col0, 0, a.dy.red, lds, acc0, acc1);
   Tail t{};
-  if (a.mask != nullptr) {
+  if (a.mask != nullptr && a.mask_bits) {
+    t.gate_bits = reinterpret_cast<const uint32_t*>(a.mask);
+    t.bits_ld = (int32_t)a.mask_ld;
+    t.mask_scale = a.mask_scale;
+  } else if (a.mask != nullptr) {
     t.residual = a.mask;
     t.res_ld = a.mask_ld;
     t.residual_is_mask = true;
@@ -1095,8 +1100,12 @@ static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t
                            float gate_pos, float gate_neg) {
   const char* what = "hivt_linear_fwd";
   HIVT_REQUIRE(M >= 0 && M < ((int64_t)1 << 31) && N > 0 && K > 0, HIVT_ERR_ARG, "%s: bad sizes", what);
+  const bool sign_bits = (epilogue & HIVT_EPI_SIGN_BITS) != 0;
+  epilogue &= ~HIVT_EPI_SIGN_BITS;
   HIVT_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LN_RELU, HIVT_ERR_ARG, "%s: unknown epilogue %d", what,
                epilogue);
+  HIVT_REQUIRE(!sign_bits || (epilogue == EPI_RELU && stats != nullptr), HIVT_ERR_ARG,
+               "%s: sign bits go with the ReLU epilogue and arrive where `stats` points", what);
   if (M == 0) return HIVT_OK;
   HIVT_REQUIRE(x && w && y, HIVT_ERR_ARG, "%s: null pointer", what);
   HIVT_REQUIRE(add_index == nullptr || (add != nullptr && add_rows >= 1), HIVT_ERR_ARG,
@@ -1122,6 +1131,11 @@ static int linear_fwd_impl(const float* x, int64_t x_ld, const float* w, int64_t
   }
   a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.y = y; a.y_ld = y_ld; a.z = z; a.z_ld = z_ld; a.stats = stats; a.M = (int32_t)M; a.N = N;
+  if (sign_bits) {
+    a.t.sign_bits = reinterpret_cast<uint32_t*>(stats);
+    a.t.bits_ld = (N + 31) / 32;
+    a.stats = nullptr;
+  }
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.x.vec_ok && a.w.vec_ok;
   const int mask = g_matmul_bf16.load(std::memory_order_relaxed);
@@ -1198,6 +1212,10 @@ static int linear_bwd_data_impl(const float* dy, int64_t dy_ld, const float* w, 
   HIVT_REQUIRE(mask == nullptr || add == nullptr, HIVT_ERR_UNSUPPORTED, "%s: mask and add are exclusive", what);
   a.mask = mask; a.mask_ld = mask_ld; a.mask_scale = mask_scale; a.mask_neg_scale = mask_neg_scale;
   a.add = add; a.add_ld = add_ld;
+  a.mask_bits = (half_flags & HIVT_MASK_BITS) ? 1 : 0;
+  HIVT_REQUIRE(!a.mask_bits || (mask != nullptr && mask_ld >= (K + 31) / 32), HIVT_ERR_ARG,
+               "%s: a bit mask needs at least ceil(K / 32) words per row", what);
+  half_flags &= ~HIVT_MASK_BITS;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = a.dy.vec_ok && a.w.vec_ok;
   const bool bf16 = (g_matmul_bf16.load(std::memory_order_relaxed) & HIVT_BF16_DGRAD) != 0;

@@ -352,6 +352,12 @@ struct Tail {
   float mask_neg_scale = 0.0f;
   // the result is stored as bfloat16 (nearest even): `out` points at 2-byte elements, out_ld counts elements
   bool out_half = false;
+  // One bit per element instead of a whole tensor as the gate of a ReLU [+ dropout]: bit (col & 31) of word
+  // [row][col >> 5] (bits_ld words per row).  sign_bits: the forward writes value > 0 of what it stores (before a
+  // residual is added).  gate_bits: the gradient is multiplied by mask_scale where the bit is set and is zero elsewhere.
+  uint32_t* sign_bits = nullptr;
+  const uint32_t* gate_bits = nullptr;
+  int32_t bits_ld = 0;
 };
 
 __device__ __forceinline__ unsigned short to_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
@@ -695,6 +701,33 @@ struct Core {
         }
       }
     }
+    if (t.sign_bits != nullptr) {  // (interior tile: every lane is active and every word is whole)
+      uint32_t* corner = t.sign_bits + (int64_t)(row0 + lrow) * t.bits_ld + ((col0 + wc * 64) >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned long long b0 = __ballot(v0[r] > 0.0f), b1 = __ballot(v1[r] > 0.0f);
+        if (lo == 0) {
+          uint32_t* word = corner + ((r & 3) + 8 * (r >> 2)) * t.bits_ld;
+          word[0] = hi ? (uint32_t)(b0 >> 32) : (uint32_t)b0;
+          word[1] = hi ? (uint32_t)(b1 >> 32) : (uint32_t)b1;
+        }
+      }
+    }
+    if (t.gate_bits != nullptr) {
+      const uint32_t* corner = t.gate_bits + (int64_t)(row0 + lrow) * t.bits_ld + ((col0 + wc * 64) >> 5);
+      uint32_t g0[16], g1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t* word = corner + ((r & 3) + 8 * (r >> 2)) * t.bits_ld;
+        g0[r] = word[0];
+        g1[r] = word[1];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        v0[r] = ((g0[r] >> lo) & 1u) ? v0[r] * t.mask_scale : 0.0f;
+        v1[r] = ((g1[r] >> lo) & 1u) ? v1[r] * t.mask_scale : 0.0f;
+      }
+    }
     if (t.residual != nullptr) {
       const float* corner = t.residual + (int64_t)row0 * t.res_ld + col0;
       const int ld = (int)t.res_ld, off = lrow * ld + lcol;
@@ -810,6 +843,21 @@ struct Core {
           const uint64_t base = (uint64_t)gr * (uint64_t)cols;
           v0 = dropout_uniform(seed, base + (uint64_t)c0) >= t.drop_p ? v0 * keep_scale : 0.0f;
           v1 = dropout_uniform(seed, base + (uint64_t)c1) >= t.drop_p ? v1 * keep_scale : 0.0f;
+        }
+        const int w0 = c0 >> 5, w1 = c1 >> 5;  // (uniform over the half wave: its lanes hold 32 aligned columns)
+        if (t.sign_bits != nullptr) {
+          const unsigned long long b0 = __ballot(ok0 && v0 > 0.0f), b1 = __ballot(ok1 && v1 > 0.0f);
+          if (lo == 0) {
+            uint32_t* word = t.sign_bits + (int64_t)gr * t.bits_ld;
+            if (w0 < t.bits_ld) word[w0] = hi ? (uint32_t)(b0 >> 32) : (uint32_t)b0;
+            if (w1 < t.bits_ld) word[w1] = hi ? (uint32_t)(b1 >> 32) : (uint32_t)b1;
+          }
+        }
+        if (t.gate_bits != nullptr) {
+          const uint32_t* word = t.gate_bits + (int64_t)gr * t.bits_ld;
+          const uint32_t g0 = w0 < t.bits_ld ? word[w0] : 0u, g1 = w1 < t.bits_ld ? word[w1] : 0u;
+          v0 = ((g0 >> lo) & 1u) ? v0 * t.mask_scale : 0.0f;
+          v1 = ((g1 >> lo) & 1u) ? v1 * t.mask_scale : 0.0f;
         }
         if (t.residual != nullptr) {
           if (t.residual_is_mask) {

@@ -615,7 +615,8 @@ def _half_gradients() -> bool:
     return (_matmul_mask & 6) == 6
 
 
-HALF_DY, HALF_DX = 1, 2
+HALF_DY, HALF_DX, MASK_BITS = 1, 2, 4
+EPI_SIGN_BITS = 0x100
 
 _PRECISIONS = {"fp32": 0, "bf16": 14, "bf16-plain": 7, "bf16-fwd": 1, "bf16-bwd": 6, "bf16-split-fwd": 8}
 
@@ -2045,13 +2046,17 @@ class _PreNormFeedForward(torch.autograd.Function):
         stats = torch.empty(m, 2, dtype=torch.float32, device=dev)
         h = torch.empty(m, hdim, dtype=torch.float32, device=dev)
         y = torch.empty(m, d, dtype=torch.float32, device=dev)
+        # while the gradient products run in bf16 mode, the gradient through ReLU / dropout reads one bit per hidden
+        # element (written here) instead of the hidden rows themselves
+        bits = torch.empty(m, (hdim + 31) // 32, dtype=torch.int32, device=dev) if _half_gradients() else None
         _lib.call("hivt_ln_fwd", _p(x2), x2.stride(0), _p(gamma_c), _p(beta_c), float(eps), m, d, _p(xn), d, _p(stats), s)
         _lib.call("hivt_linear_fwd", _p(xn), d, _p(w1c), w1c.stride(0), _p(b1c), None, 0, None, 0, None, None, 0.0,
-                  EPI_RELU, 1.0, float(p1), int(seed1), _seed_ptr(p1), None, 0, m, hdim, d, _p(h), hdim, None, 0, None, s)
+                  EPI_RELU | (EPI_SIGN_BITS if bits is not None else 0), 1.0, float(p1), int(seed1), _seed_ptr(p1), None,
+                  0, m, hdim, d, _p(h), hdim, None, 0, _p(bits), s)
         _lib.call("hivt_linear_fwd", _p(h), hdim, _p(w2c), w2c.stride(0), _p(b2c), None, 0, None, 0, None, None, 0.0,
                   EPI_NONE, 1.0, float(p2), int(seed2), _seed_ptr(p2), _p(x2), x2.stride(0), m, d, hdim, _p(y), d, None,
                   0, None, s)
-        ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, h, w1c, w2c, DEVICE_SEED if p2 > 0.0 else None)
+        ctx.save_for_backward(x2, stats, gamma_c, beta_c, xn, h, w1c, w2c, DEVICE_SEED if p2 > 0.0 else None, bits)
         ctx.cfg = (tuple(lead), float(p1), float(p2), int(seed2))
         ctx.param_leaves = _all_leaves(w1, b1, w2, b2)
         ctx.norm_leaves = _all_leaves(gamma, beta)
@@ -2060,7 +2065,7 @@ class _PreNormFeedForward(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x2, stats, gamma, beta, xn, h, w1, w2, seed_dev = ctx.saved_tensors
+        x2, stats, gamma, beta, xn, h, w1, w2, seed_dev, bits = ctx.saved_tensors
         lead, p1, p2, seed2 = ctx.cfg
         m, d = x2.shape
         hdim = w1.shape[0]
@@ -2083,7 +2088,11 @@ class _PreNormFeedForward(torch.autograd.Function):
         dw2, db2 = _weight_grad(dz2, dz2.stride(0), h, hdim, m, d, hdim, dev, leaves=ctx.param_leaves)
         dz1 = torch.empty(m, hdim, dtype=torch.bfloat16 if half else torch.float32, device=dev)
         dxn = torch.empty(m, d, dtype=torch.float32, device=dev)
-        if half:
+        if half and bits is not None:
+            _lib.call("hivt_linear_bwd_data_half", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(bits),
+                      bits.shape[1], 1.0 / (1.0 - p1), None, 0, _p(dz1), hdim,
+                      HALF_DX | MASK_BITS | (HALF_DY if half2 else 0), s)
+        elif half:
             _lib.call("hivt_linear_bwd_data_half", _p(dz2), dz2.stride(0), _p(w2), w2.stride(0), m, d, hdim, _p(h), hdim,
                       1.0 / (1.0 - p1), None, 0, _p(dz1), hdim, HALF_DX | (HALF_DY if half2 else 0), s)
         else:

@@ -361,6 +361,10 @@ int hivt_gated_update_bwd(const float* d_out, const float* agg, int64_t agg_stri
 #define HIVT_EPI_RELU 1
 #define HIVT_EPI_LN 2
 #define HIVT_EPI_LN_RELU 3
+/* or-ed into HIVT_EPI_RELU: `stats` then points at uint32 [M, ceil(N / 32)] and receives one bit per stored element,
+ * bit (n & 31) of word [m][n >> 5] = (y[m][n] > 0) after ReLU and dropout -- all that the gradient through the
+ * activation needs of y (hivt_linear_bwd_data_half with HIVT_MASK_BITS reads it instead of the [M, N] tensor). */
+#define HIVT_EPI_SIGN_BITS 0x100
 
 /* y = epilogue(x w^T + bias [+ add]) for x float [M,K] (row stride x_ld), w float [N,K] (nn.Linear
  * layout, row stride w_ld), bias [N] or NULL, add [M,N] or NULL; with add_index (int32 [M], optional)
@@ -472,6 +476,9 @@ int hivt_ln_bwd_half(const float* dy, int64_t dy_ld, const float* z, int64_t z_l
  * count elements, rows start on 8-byte boundaries. */
 #define HIVT_HALF_DY 1
 #define HIVT_HALF_DX 2
+/* hivt_linear_bwd_data_half: `mask` points at the bits written under HIVT_EPI_SIGN_BITS (uint32 words, mask_ld
+ * words per row): dx *= mask_scale where the bit is set, dx = 0 elsewhere. */
+#define HIVT_MASK_BITS 4
 int hivt_linear_bwd_data_half(const void* dy, int64_t dy_ld, const float* w, int64_t w_ld, int64_t M, int32_t N,
                               int32_t K, const float* mask, int64_t mask_ld, float mask_scale, const float* add,
                               int64_t add_ld, void* dx, int64_t dx_ld, int32_t half_flags, hivt_stream_t stream);

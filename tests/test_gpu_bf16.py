@@ -470,3 +470,40 @@ def test_edge_attention_node_equals_projection_then_attention(n_rows, max_deg, D
             assert rel(a, b) < 1e-3, i  # one bfloat16 step (2^-8 of one term among hundreds)
     if pad:
         assert float(half[2][e:].abs().max()) == 0.0  # rows of the padding receive exact zeros
+
+
+@pytest.mark.parametrize("m,d", [(1000, 128), (2563, 64), (77, 24)])
+def test_feed_forward_gate_bits_equal_the_hidden_rows_as_gate(m, d):
+    """bf16 mode: the gradient through ReLU / dropout of the feed-forward block reads one bit per hidden element,
+    written by the forward product's epilogue, instead of the hidden rows: same gradients bit for bit."""
+    from hivt_gan_amd import ops
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(9)
+    norm = torch.nn.LayerNorm(d).to(dev)
+    lin1, lin2 = torch.nn.Linear(d, 4 * d).to(dev), torch.nn.Linear(4 * d, d).to(dev)
+    x0 = torch.randn(m, d, device=dev)
+    weight = torch.randn(m, d, device=dev)
+    prev = ops.set_matmul_precision("bf16")
+    plain = ops._half_gradients
+    try:
+        def run(with_bits):
+            for p in list(norm.parameters()) + list(lin1.parameters()) + list(lin2.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            torch.manual_seed(21)  # same dropout seeds in both runs
+            if not with_bits:
+                ops._half_gradients = lambda: False  # forward writes no bits; backward gates by the hidden rows
+            try:
+                y = ops.pre_norm_feed_forward(x, norm, lin1, 0.1, lin2, 0.1, True)
+            finally:
+                ops._half_gradients = plain
+            (y * weight).sum().backward()
+            return [y.detach(), x.grad] + [p.grad.clone() for p in list(norm.parameters()) + list(lin1.parameters())
+                                          + list(lin2.parameters())]
+
+        a, b = run(True), run(False)
+    finally:
+        ops._half_gradients = plain
+        ops.set_matmul_precision(prev)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), i
