@@ -892,62 +892,75 @@ __global__ __launch_bounds__(256) void ln_fwd128_kernel(const float* __restrict_
   }
 }
 
-// out[code][c] = sum over rows m with index[m] == code of x[m][c], for a handful of codes (<= 16):
-// the gradient of a small embedding table whose rows were added per row of a big tensor.  A wave
-// strides over rows with one register accumulator per (code, owned column); selection by comparison
-// instead of indexed accumulation keeps everything in registers and the sums in a fixed order.
+// out[code][c] = sum over rows m with index[m] == code of x[m][c], for a handful of codes (<= 32): the gradient
+// of a small embedding table whose rows were added per row of a big tensor.  Every wave owns a contiguous run of
+// rows and walks it in order with ONE register accumulator for the code it is currently collecting; when the code
+// changes the accumulator is added to the wave's own [code][column] table in LDS.  Rows without a code (index
+// outside [0, R)) leave the current run as it is, so the common inputs -- a step's token on the padded agents of
+// that step, a category per edge -- cost two additions per element or one LDS update per change of code, where one
+// selected accumulator per code cost 2 R vector instructions per element.  Sums are formed in a fixed order.
 constexpr int kMaxCodes = 32;
 
-template <int NPL, int CODES>  // CODES: compile-time bound on R (16 or 32): one register accumulator per code
+template <int NPL>
 __global__ __launch_bounds__(256) void rowsum_by_code_kernel(const float* __restrict__ x, int64_t x_ld,
                                                              const int32_t* __restrict__ index, int64_t M, int N,
                                                              int R, float* __restrict__ partial /*[grid][R][N]*/) {
-  __shared__ float red[CODES][64 * NPL];
+  extern __shared__ float table[];  // [4 waves][R][64 * NPL]
+  constexpr int W = 64 * NPL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * NPL;
-  float acc[CODES][NPL];
+  float* mine = table + (size_t)wave * R * W;
+  for (int i = lane; i < R * W; i += 64) mine[i] = 0.0f;
+  const int64_t per_wave = (M + (int64_t)gridDim.x * 4 - 1) / ((int64_t)gridDim.x * 4);
+  const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * per_wave;
+  const int64_t last = first + per_wave < M ? first + per_wave : M;
+  float acc[NPL];
 #pragma unroll
-  for (int r = 0; r < CODES; ++r)
+  for (int j = 0; j < NPL; ++j) acc[j] = 0.0f;
+  int current = -1;
+  auto flush = [&]() {
+    if (current >= 0) {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) acc[r][j] = 0.0f;
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t m0 = (int64_t)blockIdx.x * 4 + wave; m0 < M; m0 += 2 * stride) {
-    float v[2][NPL];
-    int code[2];
+      for (int j = 0; j < NPL; ++j) {
+        mine[current * W + c0 + j] += acc[j];
+        acc[j] = 0.0f;
+      }
+    }
+  };
+  constexpr int U = 4;  // rows requested together
+  for (int64_t m0 = first; m0 < last; m0 += U) {
+    float v[U][NPL];
+    int code[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int64_t m = m0 + u * stride;
-      const bool ok = m < M;
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = m0 + u;
+      const bool ok = m < last;
       const int64_t mc = ok ? m : m0;
-      code[u] = ok ? index[mc] : -1;
+      const int c = index[mc];
+      code[u] = (ok && c >= 0 && c < R) ? c : -1;
 #pragma unroll
       for (int j = 0; j < NPL; ++j) v[u][j] = c0 + j < N ? x[mc * x_ld + c0 + j] : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u) {
+      const int c = __builtin_amdgcn_readfirstlane(code[u]);  // (the same for every lane: one row, one code)
+      if (c < 0) continue;
+      if (c != current) {
+        flush();
+        current = c;
+      }
 #pragma unroll
-      for (int r = 0; r < CODES; ++r)
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) acc[r][j] += (code[u] == r) ? v[u][j] : 0.0f;
-  }
-  // the four waves add their sums one after the other: ((w0 + w1) + w2) + w3, a fixed order
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int r = 0; r < CODES; ++r)
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          if (w == 0)
-            red[r][c0 + j] = acc[r][j];
-          else
-            red[r][c0 + j] += acc[r][j];
-        }
+      for (int j = 0; j < NPL; ++j) acc[j] += v[u][j];
     }
-    __syncthreads();
   }
+  flush();
+  __syncthreads();
+  // the four waves' tables in wave order: ((w0 + w1) + w2) + w3
   for (int i = threadIdx.x; i < R * N; i += 256) {
     const int r = i / N, c = i % N;
-    partial[((int64_t)blockIdx.x * R + r) * N + c] = red[r][c];
+    const float* t = table + r * W + c;
+    partial[((int64_t)blockIdx.x * R + r) * N + c] =
+        ((t[0] + t[(size_t)R * W]) + t[(size_t)2 * R * W]) + t[(size_t)3 * R * W];
   }
 }
 
@@ -1743,18 +1756,12 @@ extern "C" int hivt_rowsum_by_code(const float* x, int64_t x_ld, const int32_t* 
   int64_t blocks = (M + 7) / 8;
   if (blocks > 512) blocks = 512;
   float* partial = reinterpret_cast<float*>(workspace);
-  if (N <= 64 && R <= 16)
-    hipLaunchKernelGGL((rowsum_by_code_kernel<1, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
-                       partial);
-  else if (N <= 64)
-    hipLaunchKernelGGL((rowsum_by_code_kernel<1, 32>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
-                       partial);
-  else if (R <= 16)
-    hipLaunchKernelGGL((rowsum_by_code_kernel<2, 16>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
-                       partial);
+  if (N <= 64)
+    hipLaunchKernelGGL((rowsum_by_code_kernel<1>), dim3((unsigned)blocks), dim3(256), (size_t)4 * R * 64 * sizeof(float), s,
+                       x, x_ld, index, M, N, R, partial);
   else
-    hipLaunchKernelGGL((rowsum_by_code_kernel<2, 32>), dim3((unsigned)blocks), dim3(256), 0, s, x, x_ld, index, M, N, R,
-                       partial);
+    hipLaunchKernelGGL((rowsum_by_code_kernel<2>), dim3((unsigned)blocks), dim3(256), (size_t)4 * R * 128 * sizeof(float),
+                       s, x, x_ld, index, M, N, R, partial);
   HIVT_CHECK_LAUNCH(what);
   reduce_partials(partial, (int)blocks, R * N, out, s);
   HIVT_CHECK_LAUNCH(what);
