@@ -2,6 +2,12 @@
 
 Everything here requires tensors resident on the GPU; there is no CPU implementation behind these
 functions.  PyTorch supplies device memory, the current stream and autograd bookkeeping only.
+
+This module holds the attention, dense-layer and block-level nodes together with the state they share (the queue of
+deferred weight gradients, the dropout seeds, the timing hook).  The stateless wrappers live next to it and are
+re-exported here, so that ``ops.<name>`` reaches everything: ``ops_edges`` (edge construction, gather + rotate),
+``ops_rows`` (tokens, row subsets, batch preparation, decoder inputs / outputs), ``ops_losses`` (supervised loss,
+adversarial objectives), ``ops_spectral`` (spectral normalisation of the critics' layers).
 """
 from __future__ import annotations
 
@@ -14,286 +20,25 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _lib
+from ._opsbase import (UnsupportedShapeError, _ld, _need_gpu, _p, _ptr_array, _rows, _rows2, _stream, _unsupported,  # noqa: F401
+                       _workspace)
+from .ops_edges import (  # noqa: F401  (every name stays reachable as ops.<name>)
+    edges_temporal, edges_radius, csr_build, edges_all_pairs_csr, EdgeSet, make_edge_set,
+    _EdgeGatherRotate, edge_gather_rotate, edge_relpose)
+from .ops_losses import (  # noqa: F401  (every name stays reachable as ops.<name>)
+    _SupervisedLoss, supervised_loss, supervised_loss_packed, _HingeR1Loss, hinge_r1_loss,
+    _WeightedMean, weighted_mean, _HingeR1Multi, hinge_r1_multi, _GeneratorTotal, generator_total)
+from .ops_spectral import (  # noqa: F401  (every name stays reachable as ops.<name>)
+    _round4, _aligned_parts, _SpectralNormalize, _SpectralNormalizeRounds,
+    spectral_normalize_rounds, spectral_normalize)
+from .ops_rows import (  # noqa: F401  (every name stays reachable as ops.<name>)
+    _step_codes, _codes, _rowsum_by_code, step_tokens_supported, _MaskedStepTokens,
+    masked_step_tokens, _AppendTokenAddSteps, append_token_add_steps, RowSubset, row_subset,
+    _MaskedRowTokens, masked_row_tokens, _ExpandRowsTokens, expand_rows_with_tokens, step_guards,
+    _u8, _unit_scalars, unit_scalar, batch_prepare_supported, batch_prepare, row_subset_fixed,
+    center_rows, _RowsPutTokens, rows_put_tokens, _TemporalInput, temporal_input, _CategoryTable,
+    category_table, _DecoderOutput, decoder_output)
 
-
-def _p(t: Optional[torch.Tensor], byte_offset: int = 0):
-    """Device address as a plain integer (what a ``c_void_p`` parameter converts fastest from)."""
-    if t is None:
-        return None
-    return t.data_ptr() + byte_offset
-
-
-def _stream(t: torch.Tensor):
-    """Raw handle of the calling thread's current stream on ``t``'s device."""
-    return torch._C._cuda_getCurrentRawStream(t.device.index)
-
-
-class UnsupportedShapeError(NotImplementedError):
-    """A GPU tensor whose shape no kernel of the library is built for.  The library does not quietly hand
-    such a tensor to the framework's operators: a model outside the built shapes (embed_dim above 128 for
-    the LayerNorm kernels, a temporal sequence above 32 steps, ...) must fail visibly, not run a different
-    code path."""
-
-
-def _unsupported(what: str) -> "UnsupportedShapeError":
-    return UnsupportedShapeError(f"hivt_gan_amd has no kernel for {what}; the library does not fall back to the "
-                                 "framework's operators on GPU tensors")
-
-
-def _need_gpu(*tensors: torch.Tensor) -> None:
-    for t in tensors:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError("hivt_gan_amd kernels run on the GPU only (got a CPU tensor); "
-                               "there is no CPU fallback in the product path")
-
-
-def _workspace(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-
-
-def _ld(t: torch.Tensor) -> int:
-    """Row stride of a 2-D tensor as a kernel wants it (a single row reports its width)."""
-    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
-
-
-def _rows(t: torch.Tensor) -> torch.Tensor:
-    """A 2-D float32 view whose last dimension is contiguous (row stride arbitrary)."""
-    if t.dtype != torch.float32:
-        raise TypeError(f"expected float32, got {t.dtype}")
-    if t.dim() != 2:
-        raise ValueError(f"expected a 2-D tensor, got shape {tuple(t.shape)}")
-    if (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.data_ptr() % 16 != 0:
-        t = t.contiguous()
-    return t
-
-
-# --------------------------------------------------------------------------------------------
-# Edge construction
-# --------------------------------------------------------------------------------------------
-def edges_temporal(edge_index: torch.Tensor, padding_mask: torch.Tensor, positions: torch.Tensor, t0: int, T: int,
-                   radius: Optional[float]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Validity sub-graph + relative positions + radius filter for timesteps ``t0..t0+T-1`` at once.
-
-    Returns capacity-sized ``src, dst`` (int32, node ids offset by ``(t-t0)*N``), ``attr`` (float [.,2])
-    and a device int32 ``count``; only the first ``count`` entries are meaningful.
-    """
-    _need_gpu(edge_index, padding_mask, positions)
-    edge_index = edge_index.contiguous()
-    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
-        raise ValueError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
-    pm = padding_mask.contiguous()
-    pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
-    pos = positions.contiguous()
-    if pos.dtype != torch.float32 or pos.dim() != 3 or pos.shape[2] != 2:
-        raise ValueError("positions must be float32 [N, steps, 2]")
-    n = pos.shape[0]
-    if t0 < 0 or t0 + T > pm.shape[1] or t0 + T > pos.shape[1]:
-        raise ValueError("timestep range outside padding_mask / positions")
-    e0 = edge_index.shape[1]
-    cap = max(e0 * T, 1)
-    dev = pos.device
-    src = torch.empty(cap, dtype=torch.int32, device=dev)
-    dst = torch.empty(cap, dtype=torch.int32, device=dev)
-    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
-    count = torch.empty(1, dtype=torch.int32, device=dev)
-    ws_bytes = _lib.query("hivt_edges_workspace_bytes", e0 * T)
-    ws = _workspace(ws_bytes, dev)
-    _lib.call("hivt_edges_temporal", _p(edge_index), e0, _p(pm), pm.stride(0), _p(pos), pos.stride(0), pos.stride(1),
-              n, t0, T, float(radius) if radius is not None else 0.0, _p(src), _p(dst), _p(attr), _p(count), _p(ws),
-              ws.numel(), _stream(pos))
-    return src, dst, attr, count
-
-
-def edges_radius(edge_index: torch.Tensor, edge_attr: torch.Tensor, radius: Optional[float]
-                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Order-preserving radius filter of a COO edge list (lane -> actor edges)."""
-    _need_gpu(edge_index, edge_attr)
-    edge_index = edge_index.contiguous()
-    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
-        raise ValueError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
-    attr_in = edge_attr.contiguous()
-    if attr_in.dtype != torch.float32 or attr_in.shape != (edge_index.shape[1], 2):
-        raise ValueError("edge_attr must be float32 [E, 2]")
-    e0 = edge_index.shape[1]
-    cap = max(e0, 1)
-    dev = attr_in.device
-    src = torch.empty(cap, dtype=torch.int32, device=dev)
-    dst = torch.empty(cap, dtype=torch.int32, device=dev)
-    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
-    count = torch.empty(1, dtype=torch.int32, device=dev)
-    ws = _workspace(_lib.query("hivt_edges_workspace_bytes", e0), dev)
-    _lib.call("hivt_edges_radius", _p(edge_index), e0, _p(attr_in), float(radius) if radius is not None else 0.0,
-              _p(src), _p(dst), _p(attr), _p(count), _p(ws), ws.numel(), _stream(attr_in))
-    return src, dst, attr, count
-
-
-def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = None
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Stable grouping of edge positions by ``key``: returns (rowptr int32 [num_rows+1], perm int32 [E]).
-    ``count`` (device int32 scalar) marks the live prefix of a list padded to a fixed capacity."""
-    _need_gpu(key)
-    if key.dtype != torch.int32 or key.dim() != 1:
-        raise ValueError("key must be an int32 vector")
-    key = key.contiguous()
-    e = key.shape[0]
-    dev = key.device
-    rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
-    perm = torch.empty(e, dtype=torch.int32, device=dev)
-    ws = _workspace(_lib.query("hivt_csr_workspace_bytes", e, num_rows), dev)
-    _lib.call("hivt_csr_build", _p(key), e, _p(count), num_rows, _p(rowptr), _p(perm), _p(ws), ws.numel(),
-              _stream(key))
-    return rowptr, perm
-
-
-def edges_all_pairs_csr(scene_range: torch.Tensor, padding_mask: torch.Tensor, positions: torch.Tensor, t0: int,
-                        T: int, radius: Optional[float], capacity: int
-                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Agent-agent edges of timesteps ``t0..t0+T-1`` for all-pairs candidate sets, produced in CSR order
-    without a candidate list or a sort.  Returns ``rowptr`` (int32 [T*N + 1], clamped to ``capacity``),
-    ``src``, ``dst`` (int32 [capacity], ids offset by ``(t-t0)*N``), ``attr`` (float [capacity, 2]) and the
-    device int32 ``count`` of kept edges before clamping."""
-    _need_gpu(scene_range, padding_mask, positions)
-    if scene_range.dtype != torch.int32 or scene_range.dim() != 2 or scene_range.shape[1] != 2:
-        raise ValueError("scene_range must be int32 [N, 2]")
-    sr = scene_range.contiguous()
-    pm = padding_mask.contiguous()
-    pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
-    pos = positions.contiguous()
-    if pos.dtype != torch.float32 or pos.dim() != 3 or pos.shape[2] != 2:
-        raise ValueError("positions must be float32 [N, steps, 2]")
-    n = pos.shape[0]
-    if sr.shape[0] != n or pm.shape[0] != n:
-        raise ValueError("scene_range, padding_mask and positions must describe the same agents")
-    if t0 < 0 or t0 + T > pm.shape[1] or t0 + T > pos.shape[1]:
-        raise ValueError("timestep range outside padding_mask / positions")
-    dev = pos.device
-    cap = max(int(capacity), 1)
-    rowptr = torch.empty(n * T + 1, dtype=torch.int32, device=dev)
-    src = torch.empty(cap, dtype=torch.int32, device=dev)
-    dst = torch.empty(cap, dtype=torch.int32, device=dev)
-    attr = torch.empty(cap, 2, dtype=torch.float32, device=dev)
-    count = torch.empty(1, dtype=torch.int32, device=dev)
-    ws = _workspace(_lib.query("hivt_edges_all_pairs_workspace_bytes", n * T), dev)
-    _lib.call("hivt_edges_all_pairs_csr", _p(sr), _p(pm), pm.stride(0), _p(pos), pos.stride(0), pos.stride(1), n, t0, T,
-              float(radius) if radius is not None else 0.0, int(capacity), _p(rowptr), _p(src), _p(dst), _p(attr),
-              _p(count), _p(ws), ws.numel(), _stream(pos))
-    return rowptr, src, dst, attr, count
-
-
-@dataclass
-class EdgeSet:
-    """One filtered edge list grouped by target node.
-
-    ``coo_*`` are in the order the reference would hold them (filtered, order preserving);
-    ``src`` / ``dst`` are the same edges in CSR order (position i of the CSR order is position
-    ``perm[i]`` of the COO order).  A set produced directly in CSR order has ``perm`` None and its
-    ``coo_*`` lists already grouped by target."""
-    num_src: int
-    num_dst: int
-    coo_src: torch.Tensor
-    coo_dst: torch.Tensor
-    coo_attr: torch.Tensor
-    rowptr: torch.Tensor
-    perm: Optional[torch.Tensor]
-    src: Optional[torch.Tensor] = None
-    dst: Optional[torch.Tensor] = None
-    rowptr_by_src: Optional[torch.Tensor] = None
-    perm_by_src: Optional[torch.Tensor] = None
-    count: Optional[torch.Tensor] = None  # device int32: live edges when the lists are padded to a capacity
-
-    @property
-    def num_edges(self) -> int:
-        return int(self.coo_src.shape[0])
-
-    def edge_index(self) -> torch.Tensor:
-        """The filtered COO list as the reference's int64 ``[2, E]`` tensor."""
-        return torch.stack([self.coo_src, self.coo_dst]).long()
-
-    def group_by_source(self) -> None:
-        """CSR over sources of the CSR-ordered edges (for gradients of source lifts)."""
-        if self.rowptr_by_src is None:
-            self.rowptr_by_src, self.perm_by_src = csr_build(self.src, self.num_src, self.count)
-
-
-def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_src: int, num_dst: int,
-                  count: Optional[torch.Tensor] = None) -> EdgeSet:
-    """Group an already filtered int32 COO list by target (``count``: live prefix of padded lists)."""
-    rowptr, perm = csr_build(dst, num_dst, count)
-    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm, count=count)
-
-
-# --------------------------------------------------------------------------------------------
-# Kernel (a): gather + rotate
-# --------------------------------------------------------------------------------------------
-class _EdgeGatherRotate(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, x_src, attr, rot, src, dst, perm, rot_mod, count):
-        _need_gpu(x_src, attr, src, dst)
-        x2 = x_src if (x_src.dim() == 2 and x_src.stride(1) == 1 and x_src.stride(0) % 2 == 0
-                       and x_src.data_ptr() % 8 == 0) else x_src.contiguous()
-        attr = attr.contiguous()
-        rot_c = rot.contiguous() if rot is not None else None
-        e = src.shape[0]
-        out = torch.empty(e, 4, dtype=torch.float32, device=attr.device)
-        src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
-        dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
-        _lib.call("hivt_edge_gather_rotate_fwd", _p(x2), x2.stride(0), _p(attr), _p(rot_c), _p(src), _p(dst), _p(perm),
-                  int(rot_mod), e, _p(count), _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
-        ctx.save_for_backward(rot_c, src, dst, perm, count, src_csr)
-        ctx.rot_mod = int(rot_mod)
-        ctx.x_shape = tuple(x_src.shape)
-        ctx.mark_non_differentiable(src_csr, dst_csr)
-        return out, src_csr, dst_csr
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, d_out, _g1, _g2):
-        rot_c, src, dst, perm, count, src_out = ctx.saved_tensors
-        e = src.shape[0]
-        d_out = d_out.contiguous()
-        dev = d_out.device
-        d_x_edge = torch.empty(e, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        d_attr = None
-        if ctx.needs_input_grad[1]:
-            d_attr = (torch.zeros if count is not None else torch.empty)(e, 2, dtype=torch.float32, device=dev)
-        if d_x_edge is not None or d_attr is not None:
-            _lib.call("hivt_edge_gather_rotate_bwd", _p(d_out), _p(rot_c), _p(src), _p(dst), _p(perm), ctx.rot_mod, e,
-                      _p(count), _p(d_attr), _p(d_x_edge), _stream(d_out))
-        d_x = None
-        if d_x_edge is not None:
-            # rows of one source summed in ascending output position: deterministic
-            ns = ctx.x_shape[0]
-            rowptr_s, perm_s = csr_build(src_out, ns, count)
-            summed = torch.empty(ns, 4, dtype=torch.float32, device=dev)
-            _lib.call("hivt_segment_sum_rows", _p(d_x_edge), 4, 4, _p(rowptr_s), _p(perm_s), ns, _p(summed), 4,
-                      _stream(d_out))
-            d_x = torch.zeros(ctx.x_shape, dtype=torch.float32, device=dev)
-            d_x[:, :2] = summed[:, :2]
-        return d_x, d_attr, None, None, None, None, None, None
-
-
-def edge_gather_rotate(x_src: torch.Tensor, attr: torch.Tensor, rot: Optional[torch.Tensor], src: torch.Tensor,
-                       dst: torch.Tensor, perm: Optional[torch.Tensor], rot_mod: int,
-                       count: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``[x_src[src] @ R[dst % rot_mod], attr @ R[dst % rot_mod]]`` per edge in ``perm`` order -> ([E,4], src, dst).
-    Rows at or beyond ``count`` (padding of fixed-capacity lists) come out as zeros / index 0."""
-    return _EdgeGatherRotate.apply(x_src, attr, rot, src, dst, perm, rot_mod, count)
-
-
-def edge_relpose(attr: torch.Tensor, rot: torch.Tensor, angles: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
-                 perm: Optional[torch.Tensor], count: Optional[torch.Tensor] = None
-                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Global-interactor edge features ``[rel_pos @ R[dst], cos dtheta, sin dtheta]`` (inputs carry no grad)."""
-    _need_gpu(attr, rot, angles, src, dst)
-    e = src.shape[0]
-    attr, rot, angles = attr.contiguous(), rot.contiguous(), angles.contiguous()
-    out = torch.empty(e, 4, dtype=torch.float32, device=attr.device)
-    src_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
-    dst_csr = torch.empty(e, dtype=torch.int32, device=attr.device)
-    _lib.call("hivt_edge_relpose_fwd", _p(attr), _p(rot), _p(angles), _p(src), _p(dst), _p(perm), e, _p(count),
-              _p(out), _p(src_csr), _p(dst_csr), _stream(attr))
-    return out, src_csr, dst_csr
 
 
 # --------------------------------------------------------------------------------------------
@@ -508,88 +253,9 @@ def gated_update(agg: torch.Tensor, ih: torch.Tensor, hh_self: torch.Tensor) -> 
 
 
 # --------------------------------------------------------------------------------------------
-# Fused supervised loss
-# --------------------------------------------------------------------------------------------
-class _SupervisedLoss(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, y_hat, pi, y, padding_mask, t_hist, want_best_traj):
-        _need_gpu(y_hat, pi, y, padding_mask)
-        f, n, hf, ch = y_hat.shape
-        if ch != 4 or pi.shape != (n, f) or y.shape != (n, hf, 2):
-            raise ValueError("expected y_hat [F,N,H,4], pi [N,F], y [N,H,2]")
-        y_hat, pi, y = y_hat.contiguous(), pi.contiguous(), y.contiguous()
-        pm = padding_mask.contiguous()
-        pm = pm.view(torch.uint8) if pm.dtype == torch.bool else pm
-        dev = y_hat.device
-        losses = torch.empty(2, dtype=torch.float32, device=dev)
-        stats = torch.empty(4, dtype=torch.float32, device=dev)
-        best = torch.empty(n, dtype=torch.int64, device=dev)
-        soft = torch.empty(n, f, dtype=torch.float32, device=dev)
-        ws = _workspace(_lib.query("hivt_laplace_workspace_bytes", n), dev)
-        _lib.call("hivt_laplace_minmode_fwd", _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), int(t_hist), f, n, hf,
-                  _p(losses), _p(best), _p(soft), _p(stats), _p(ws), ws.numel(), _stream(y_hat))
-        traj = None
-        if want_best_traj:  # the best mode's locations (models/hivt.py:221-224), cut out next to the argmin
-            traj = torch.empty(n, hf, 2, dtype=torch.float32, device=dev)
-            _lib.call("hivt_select_mode_fwd", _p(y_hat), _p(best), f, n, hf, 4, _p(traj), _stream(y_hat))
-        ctx.save_for_backward(y_hat, pi, y, pm, best, soft, stats)
-        ctx.t_hist = int(t_hist)
-        ctx.mark_non_differentiable(best)
-        ctx.set_materialize_grads(False)
-        return losses, best, traj
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g_losses, _g_best, g_traj):
-        y_hat, pi, y, pm, best, soft, stats = ctx.saved_tensors
-        f, n, hf, _ = y_hat.shape
-        g = g_losses.contiguous().float() if g_losses is not None else \
-            torch.zeros(2, dtype=torch.float32, device=y_hat.device)
-        d_y_hat = torch.empty_like(y_hat)
-        d_pi = torch.empty_like(pi)
-        _lib.call("hivt_laplace_minmode_bwd", _p(g), _p(y_hat), _p(pi), _p(y), _p(pm), pm.stride(0), ctx.t_hist, f, n,
-                  hf, _p(best), _p(soft), _p(stats), _p(d_y_hat), _p(d_pi), _stream(y_hat))
-        if g_traj is not None:  # added where the best mode's locations lie
-            g_traj = g_traj.contiguous()
-            _lib.call("hivt_select_mode_bwd", _p(g_traj), _p(best), f, n, hf, 4, _p(d_y_hat), _stream(y_hat))
-        return d_y_hat, d_pi, None, None, None, None
-
-
-def supervised_loss(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
-                    historical_steps: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(reg_loss, cls_loss, best_mode) of the best-of-F Laplace NLL + soft-target CE, without host sync."""
-    losses, best, _ = _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps, False)
-    return losses[0], losses[1], best
-
-
-def supervised_loss_packed(y_hat: torch.Tensor, pi: torch.Tensor, y: torch.Tensor, padding_mask: torch.Tensor,
-                           historical_steps: int, want_best_traj: bool = True
-                           ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
-    """``(losses [2] = (reg_loss, cls_loss), best_mode [N], best_traj [N, H, 2] or None)``: the same losses as one
-    tensor (consumers that take it whole save the two select nodes and their gradient sums) plus the best mode's
-    predicted locations ``y_hat[best_mode, arange(N), :, :2]`` (``models/hivt.py:221-224``), whose gradient is added
-    inside this node's backward instead of through an index node."""
-    return _SupervisedLoss.apply(y_hat, pi, y, padding_mask, historical_steps, bool(want_best_traj))
-
-
-# --------------------------------------------------------------------------------------------
 # Dense projections on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------
 EPI_NONE, EPI_RELU, EPI_LN, EPI_LN_RELU = 0, 1, 2, 3
-
-
-def _rows2(t: torch.Tensor) -> torch.Tensor:
-    """2-D float32 view (leading dims flattened) whose last dimension has stride 1."""
-    if t.dtype != torch.float32:
-        raise TypeError(f"expected float32, got {t.dtype}")
-    if t.dim() != 2:
-        t = t.reshape(-1, t.shape[-1])
-    if t.shape[1] > 1 and t.stride(1) != 1:
-        t = t.contiguous()
-    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
-        t = t.contiguous()
-    return t
 
 
 def linear_fused_supported(n_out: int, layer_norm: bool) -> bool:
@@ -1400,169 +1066,6 @@ def temporal_attention_supported(seq_len: int, d_model: int, num_heads: int) -> 
 
 
 # --------------------------------------------------------------------------------------------
-# Spectral normalisation of a stack of linear layers (the critics)
-# --------------------------------------------------------------------------------------------
-def _ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-
-
-def _round4(n: int) -> int:
-    return (n + 3) // 4 * 4
-
-
-def _aligned_parts(buf: torch.Tensor, sizes):
-    parts, off = [], 0
-    for n in sizes:
-        parts.append(buf[off:off + n])
-        off += _round4(n)
-    return parts
-
-
-class _SpectralNormalize(torch.autograd.Function):
-    """``(w_0 / sigma_0, ..., w_{L-1} / sigma_{L-1})`` for L weight matrices in one launch; in training
-    mode one power iteration updates the ``u`` / ``v`` buffers in place first."""
-
-    @staticmethod
-    def forward(ctx, state, *weights):
-        us, vs, training, eps = state
-        _need_gpu(*weights)
-        layers = len(weights)
-        ws = [w.contiguous() for w in weights]
-        dev = ws[0].device
-        rows = (ctypes.c_int32 * layers)(*[w.shape[0] for w in ws])
-        cols = (ctypes.c_int32 * layers)(*[w.shape[1] for w in ws])
-        wn = [torch.empty_like(w) for w in ws]
-        # one buffer for every layer's copies of u and v, each 16-byte aligned
-        sizes = [w.shape[0] for w in ws] + [w.shape[1] for w in ws]
-        used = torch.empty(sum(_round4(n) for n in sizes), dtype=torch.float32, device=dev)
-        parts = _aligned_parts(used, sizes)
-        u_used, v_used = parts[:layers], parts[layers:]
-        sigma = torch.empty(layers, dtype=torch.float32, device=dev)
-        _lib.call("hivt_spectral_norm_fwd", layers, _ptr_array(ws), _ptr_array(us), _ptr_array(vs), rows, cols,
-                  1 if training else 0, float(eps), _ptr_array(wn), _ptr_array(u_used), _ptr_array(v_used), _p(sigma),
-                  _stream(ws[0]))
-        ctx.save_for_backward(used, sigma, *ws)
-        ctx.sizes = sizes
-        return tuple(wn)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, *d_wn):
-        used, sigma, *ws = ctx.saved_tensors
-        layers = len(ws)
-        parts = _aligned_parts(used, ctx.sizes)
-        u_used, v_used = parts[:layers], parts[layers:]
-        keep = [i for i, g in enumerate(d_wn) if g is not None]
-        grads = [None] * layers
-        if keep:
-            gs = [d_wn[i].contiguous() for i in keep]
-            outs = [torch.empty_like(ws[i]) for i in keep]
-            sig = sigma if len(keep) == layers else sigma[keep]
-            rows = (ctypes.c_int32 * len(keep))(*[ws[i].shape[0] for i in keep])
-            cols = (ctypes.c_int32 * len(keep))(*[ws[i].shape[1] for i in keep])
-            _lib.call("hivt_spectral_norm_bwd", len(keep), _ptr_array(gs), _ptr_array([ws[i] for i in keep]),
-                      _ptr_array([u_used[i] for i in keep]), _ptr_array([v_used[i] for i in keep]), _p(sig), rows, cols,
-                      _ptr_array(outs), _stream(gs[0]))
-            for i, o in zip(keep, outs):
-                grads[i] = o
-        return (None, *grads)
-
-
-class _SpectralNormalizeRounds(torch.autograd.Function):
-    """``rounds`` successive calls of ``_SpectralNormalize`` on the same weights (every round advances ``u`` / ``v`` by
-    one power iteration and normalises with ITS sigma) as one node of the graph: outputs round-major, and the
-    gradient of a weight comes out as the sum over the rounds, added in one multi-tensor launch instead of one
-    accumulation per weight."""
-
-    @staticmethod
-    def forward(ctx, state, *weights):
-        us, vs, training, eps, rounds = state
-        _need_gpu(*weights)
-        layers = len(weights)
-        ws = [w.contiguous() for w in weights]
-        dev = ws[0].device
-        rows = (ctypes.c_int32 * layers)(*[w.shape[0] for w in ws])
-        cols = (ctypes.c_int32 * layers)(*[w.shape[1] for w in ws])
-        sizes = [w.shape[0] for w in ws] + [w.shape[1] for w in ws]
-        per_round = sum(_round4(n) for n in sizes)
-        used = torch.empty(rounds * per_round, dtype=torch.float32, device=dev)
-        sigma = torch.empty(rounds * layers, dtype=torch.float32, device=dev)
-        outs = []
-        for r in range(rounds):
-            wn = [torch.empty_like(w) for w in ws]
-            parts = _aligned_parts(used[r * per_round:(r + 1) * per_round], sizes)
-            _lib.call("hivt_spectral_norm_fwd", layers, _ptr_array(ws), _ptr_array(us), _ptr_array(vs), rows, cols,
-                      1 if training else 0, float(eps), _ptr_array(wn), _ptr_array(parts[:layers]),
-                      _ptr_array(parts[layers:]), _p(sigma[r * layers:]), _stream(ws[0]))
-            outs += wn
-        ctx.save_for_backward(used, sigma, *ws)
-        ctx.sizes, ctx.rounds, ctx.per_round = sizes, rounds, per_round
-        return tuple(outs)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, *d_wn):
-        used, sigma, *ws = ctx.saved_tensors
-        layers, rounds = len(ws), ctx.rounds
-        grads = [None] * layers
-        for r in range(rounds):
-            d_r = d_wn[r * layers:(r + 1) * layers]
-            keep = [i for i, g in enumerate(d_r) if g is not None]
-            if not keep:
-                continue
-            parts = _aligned_parts(used[r * ctx.per_round:(r + 1) * ctx.per_round], ctx.sizes)
-            u_used, v_used = parts[:layers], parts[layers:]
-            gs = [d_r[i].contiguous() for i in keep]
-            outs = [torch.empty_like(ws[i]) for i in keep]
-            sig = sigma[r * layers:(r + 1) * layers]
-            if len(keep) != layers:
-                sig = sig[keep]
-            rows = (ctypes.c_int32 * len(keep))(*[ws[i].shape[0] for i in keep])
-            cols = (ctypes.c_int32 * len(keep))(*[ws[i].shape[1] for i in keep])
-            _lib.call("hivt_spectral_norm_bwd", len(keep), _ptr_array(gs), _ptr_array([ws[i] for i in keep]),
-                      _ptr_array([u_used[i] for i in keep]), _ptr_array([v_used[i] for i in keep]), _p(sig), rows, cols,
-                      _ptr_array(outs), _stream(gs[0]))
-            have = [i for i in keep if grads[i] is not None]
-            if have:  # one multi-tensor launch for the sums over the rounds
-                torch._foreach_add_([grads[i] for i in have], [o for i, o in zip(keep, outs) if grads[i] is not None])
-            for i, o in zip(keep, outs):
-                if grads[i] is None:
-                    grads[i] = o
-        return (None, *grads)
-
-
-def spectral_normalize_rounds(weights, us, vs, rounds: int, training: bool, eps: float = 1e-12):
-    """``rounds`` calls of ``spectral_normalize`` in a row (what ``rounds`` forward calls of a spectrally normalised
-    layer do in training mode) as one node of the autograd graph; returns one list of normalised copies per round."""
-    if len(weights) > 16 or rounds < 1:
-        raise ValueError("at most 16 layers per call, at least one round")
-    for w, u, v in zip(weights, us, vs):
-        if w.dim() != 2 or u.shape != (w.shape[0],) or v.shape != (w.shape[1],):
-            raise ValueError("weights must be [out, in] with u [out] and v [in]")
-        if w.dtype != torch.float32 or not u.is_contiguous() or not v.is_contiguous():
-            raise TypeError("spectral_normalize needs float32 weights and contiguous u / v")
-    _need_gpu(*us, *vs)
-    outs = _SpectralNormalizeRounds.apply((list(us), list(vs), bool(training), eps, int(rounds)), *weights)
-    n = len(weights)
-    return [list(outs[r * n:(r + 1) * n]) for r in range(rounds)]
-
-
-def spectral_normalize(weights, us, vs, training: bool, eps: float = 1e-12):
-    """Spectrally normalised copies of ``weights`` (a list of [out, in] matrices, at most 16).  ``us`` /
-    ``vs`` are the persistent power-iteration vectors; in training mode they advance by one iteration
-    (in place), exactly as the hook of ``torch.nn.utils.spectral_norm`` does per forward call."""
-    if len(weights) > 16:
-        raise ValueError("at most 16 layers per call")
-    for w, u, v in zip(weights, us, vs):
-        if w.dim() != 2 or u.shape != (w.shape[0],) or v.shape != (w.shape[1],):
-            raise ValueError("weights must be [out, in] with u [out] and v [in]")
-        if w.dtype != torch.float32 or not u.is_contiguous() or not v.is_contiguous():
-            raise TypeError("spectral_normalize needs float32 weights and contiguous u / v")
-    _need_gpu(*us, *vs)
-    return _SpectralNormalize.apply((list(us), list(vs), bool(training), eps), *weights)
-
-
-# --------------------------------------------------------------------------------------------
 # First stage of the embedding MLPs (two-component inputs)
 # --------------------------------------------------------------------------------------------
 def embed2_supported(in_channels, width: int) -> bool:
@@ -1952,72 +1455,6 @@ def critic_scores_multi(passes, neg_slope: float, dropout_p: float, training: bo
             result.append(outs[at])
             at += 1
     return result
-
-
-# --------------------------------------------------------------------------------------------
-# Per-scale adversarial loss terms (one launch instead of a dozen framework reductions)
-# --------------------------------------------------------------------------------------------
-class _HingeR1Loss(torch.autograd.Function):
-    """(loss, r1) of one critic scale; gradients flow into the two score vectors and the gradient norms."""
-
-    @staticmethod
-    def forward(ctx, s_real, grad_norm2, s_fake, w, count, lambda_r1):
-        _need_gpu(s_real, grad_norm2, s_fake, w, count)
-        b = s_real.shape[0]
-        s_real, grad_norm2, s_fake, w = (t.contiguous() for t in (s_real, grad_norm2, s_fake, w))
-        out = torch.empty(2, dtype=torch.float32, device=s_real.device)
-        _lib.call("hivt_hinge_r1_fwd", _p(s_real), _p(grad_norm2), _p(s_fake), _p(w), _p(count), b, float(lambda_r1),
-                  _p(out), _stream(s_real))
-        ctx.save_for_backward(s_real, s_fake, w, count)
-        ctx.lambda_r1 = float(lambda_r1)
-        loss, r1 = out[0], out[1]
-        ctx.mark_non_differentiable(r1)
-        return loss, r1
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g_loss, _g_r1):
-        s_real, s_fake, w, count = ctx.saved_tensors
-        b = s_real.shape[0]
-        g_loss = g_loss.contiguous()
-        g_real, g_norm2, g_fake = (torch.empty_like(s_real) for _ in range(3))
-        _lib.call("hivt_hinge_r1_bwd", _p(g_loss), _p(s_real), _p(s_fake), _p(w), _p(count), b, ctx.lambda_r1, _p(g_real),
-                  _p(g_norm2), _p(g_fake), _stream(s_real))
-        return g_real, g_norm2, g_fake, None, None, None
-
-
-def hinge_r1_loss(s_real: torch.Tensor, grad_norm2: torch.Tensor, s_fake: torch.Tensor, w: torch.Tensor,
-                  count: torch.Tensor, lambda_r1: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``(mean_w relu(1 - s_real) + mean_w relu(1 + s_fake) + lambda_r1 * r1, r1)`` with
-    ``r1 = mean_w grad_norm2`` and ``mean_w(v) = sum(w * v) / count`` (``count``: device scalar)."""
-    return _HingeR1Loss.apply(s_real, grad_norm2, s_fake, w, count, lambda_r1)
-
-
-class _WeightedMean(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, s, w, count, scale):
-        _need_gpu(s, w, count)
-        s, w = s.contiguous(), w.contiguous()
-        out = torch.empty((), dtype=torch.float32, device=s.device)
-        _lib.call("hivt_weighted_mean_fwd", _p(s), _p(w), _p(count), s.shape[0], float(scale), _p(out), _stream(s))
-        ctx.save_for_backward(w, count)
-        ctx.scale = float(scale)
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g_out):
-        w, count = ctx.saved_tensors
-        g_s = torch.empty_like(w)
-        _lib.call("hivt_weighted_mean_bwd", _p(g_out.contiguous()), _p(w), _p(count), w.shape[0], ctx.scale, _p(g_s),
-                  _stream(w))
-        return g_s, None, None, None
-
-
-def weighted_mean(s: torch.Tensor, w: torch.Tensor, count: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """``scale * sum(w * s) / count`` as a 0-d tensor (``count``: device scalar)."""
-    return _WeightedMean.apply(s, w, count, scale)
 
 
 # --------------------------------------------------------------------------------------------
@@ -2478,619 +1915,6 @@ def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: tor
     cfg = (int(num_heads), pa, _fresh_seed() if pa > 0.0 else 0, po, _fresh_seed() if po > 0.0 else 0, tag,
            bool(padded), node_terms)
     return _AttentionBlock.apply(center, residual, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params)
-
-
-# --------------------------------------------------------------------------------------------
-# Per-timestep tokens broadcast over agents
-# --------------------------------------------------------------------------------------------
-# The reference writes these as broadcasting torch.where / add / expand.  Their gradients with respect
-# to the tokens are sums over the agent axis of a [T, N, D] tensor, which the framework computes with a
-# multi-block reduction that clears its semaphores through a runtime memset -- a node kind that takes no
-# effect in a replayed HIP graph on this stack.  Here the sums run on hivt_rowsum_by_code (fixed order).
-_step_codes = {}
-
-
-def _codes(steps: int, n: int, device) -> torch.Tensor:
-    """int32 [steps * n]: row s * n + j carries code s."""
-    key = (steps, n, device)
-    if key not in _step_codes:
-        if len(_step_codes) > 64:
-            _step_codes.clear()
-        _step_codes[key] = torch.arange(steps, dtype=torch.int32, device=device).repeat_interleave(n)
-    return _step_codes[key]
-
-
-def _rowsum_by_code(x2: torch.Tensor, codes: torch.Tensor, num_codes: int) -> torch.Tensor:
-    m, n = x2.shape
-    out = torch.empty(num_codes, n, dtype=torch.float32, device=x2.device)
-    ws = _workspace(_lib.query("hivt_rowsum_by_code_workspace_bytes", m, n, num_codes), x2.device)
-    _lib.call("hivt_rowsum_by_code", _p(x2), x2.stride(0), _p(codes), m, n, num_codes, _p(out), _p(ws), ws.numel(),
-              _stream(x2))
-    return out
-
-
-def step_tokens_supported(x: torch.Tensor, steps: int) -> bool:
-    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] <= 128 and steps <= 32 \
-        and x.numel() > 0
-
-
-class _MaskedStepTokens(torch.autograd.Function):
-    """``where(mask[..., None], token[:, None, :], x)`` for x [T, N, D], mask [T, N], token [T, D]
-    (``models/local_encoder.py:150,230``)."""
-
-    @staticmethod
-    def forward(ctx, x, mask, token):
-        # a transposed mask view would hand its permuted layout to the result (and a copy to whoever reshapes it)
-        mask = mask.contiguous()
-        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x.contiguous())
-        ctx.save_for_backward(mask)
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        (mask,) = ctx.saved_tensors
-        t, n, d = dy.shape
-        dy = dy.contiguous()
-        dx = torch.where(mask.unsqueeze(-1), torch.zeros((), dtype=dy.dtype, device=dy.device), dy) \
-            if ctx.needs_input_grad[0] else None
-        dtoken = None
-        if ctx.needs_input_grad[2]:
-            codes = torch.where(mask.reshape(-1), _codes(t, n, dy.device), -1)
-            dtoken = _rowsum_by_code(dy.view(t * n, d), codes, t)
-        return dx, None, dtoken
-
-
-def masked_step_tokens(x: torch.Tensor, mask: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
-    """Rows (t, n) with ``mask[t, n]`` replaced by ``token[t]``; x [T, N, D], mask [T, N] bool, token [T, D]."""
-    return _MaskedStepTokens.apply(x, mask, token)
-
-
-class _AppendTokenAddSteps(torch.autograd.Function):
-    """``cat((x, last.expand(1, N, D))) + per_step[:, None, :]`` for x [T, N, D], last [D], per_step [T + 1, D]
-    (the class token and the positional embedding of ``models/local_encoder.py:231-232``)."""
-
-    @staticmethod
-    def forward(ctx, x, last, per_step):
-        t, n, d = x.shape
-        out = torch.empty(t + 1, n, d, dtype=x.dtype, device=x.device)
-        torch.add(x, per_step[:t].unsqueeze(1), out=out[:t])
-        out[t] = last + per_step[t]
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        s, n, d = dy.shape
-        dy = dy.contiguous()
-        dper = _rowsum_by_code(dy.view(s * n, d), _codes(s, n, dy.device), s)
-        return dy[:s - 1], dper[s - 1].clone(), dper
-
-
-def append_token_add_steps(x: torch.Tensor, last: torch.Tensor, per_step: torch.Tensor) -> torch.Tensor:
-    return _AppendTokenAddSteps.apply(x, last, per_step)
-
-
-# --------------------------------------------------------------------------------------------
-# Row subsets: a stage that is evaluated for some rows of a [steps * agents] node set only
-# --------------------------------------------------------------------------------------------
-@dataclass
-class RowSubset:
-    """The live rows of a node set, packed to the front of ``capacity`` rows.
-
-    ``rows`` [capacity] int32: node id of every packed row (entries at or beyond ``count`` repeat a valid id, so
-    whatever is gathered through them is finite; nothing reads their results).  ``new_id`` [num_rows] int32: packed
-    position of a node (nodes outside the subset: some position inside the packed range).  ``rowptr`` [capacity + 1]:
-    the CSR row pointer of an edge set over the full node set, re-indexed to packed rows (rows outside the subset
-    must own no edges; packed rows beyond ``count`` own none)."""
-    rows: torch.Tensor
-    new_id: torch.Tensor
-    live: torch.Tensor           # [capacity] bool: packed row < count
-    count: torch.Tensor          # 0-d int32 on the device
-    capacity: int
-    num_rows: int
-    rowptr: Optional[torch.Tensor] = None
-    overflow: Optional[torch.Tensor] = None  # 0-d bool: more live rows than capacity
-
-
-def row_subset(valid: torch.Tensor, capacity: Optional[int] = None, rowptr: Optional[torch.Tensor] = None,
-               count_hint: Optional[int] = None) -> RowSubset:
-    """Packs the rows with ``valid`` (bool [M]) in ascending order.  Without ``capacity`` the packed size is the
-    live count (``count_hint`` if the caller has already read it back, else one read-back here); with it nothing
-    is read back, the packed arrays have ``capacity`` rows and ``overflow`` tells whether the live rows fit."""
-    _need_gpu(valid)
-    m = int(valid.shape[0])
-    dev = valid.device
-    pos = torch.cumsum(valid, 0, dtype=torch.int32)          # inclusive count of live rows up to each row
-    count = pos[-1] if m > 0 else torch.zeros((), dtype=torch.int32, device=dev)
-    if capacity is None:
-        capacity = int(count_hint) if count_hint is not None else int(count.item())
-    capacity = max(int(capacity), 1)
-    new_id = pos - 1
-    ids = torch.arange(m, dtype=torch.int32, device=dev)
-    # slot `capacity + 1` swallows the rows outside the subset (and live rows that do not fit)
-    slot = torch.where(valid & (new_id < capacity), new_id, capacity + 1).long()
-    buf = torch.full((capacity + 2,), m, dtype=torch.int32, device=dev)
-    buf.scatter_(0, slot, ids)
-    packed_rowptr = rowptr.index_select(0, buf[:capacity + 1]) if rowptr is not None else None
-    live = torch.arange(capacity, dtype=torch.int32, device=dev) < count
-    # entries beyond the live rows repeat the first live row: gathers through them stay finite
-    first = buf[0].clamp(max=max(m - 1, 0))
-    rows = torch.where(live, buf[:capacity], first)
-    return RowSubset(rows, new_id.clamp_(min=0, max=capacity - 1), live, count, capacity, m, packed_rowptr,
-                     (count > capacity).view(()))
-
-
-class _MaskedRowTokens(torch.autograd.Function):
-    """``where(mask[:, None], token[code], x)`` for x [M, D], mask [M] bool, code [M] int32, token [R, D]; the
-    token's gradient is a per-code row sum in a fixed order."""
-
-    @staticmethod
-    def forward(ctx, x, mask, code, token):
-        out = torch.where(mask.unsqueeze(-1), token.index_select(0, code), x)
-        ctx.save_for_backward(mask, code)
-        ctx.codes = int(token.shape[0])
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        mask, code = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = torch.where(mask.unsqueeze(-1), torch.zeros((), dtype=dy.dtype, device=dy.device), dy) \
-            if ctx.needs_input_grad[0] else None
-        dtoken = _rowsum_by_code(dy, torch.where(mask, code, -1), ctx.codes) if ctx.needs_input_grad[3] else None
-        return dx, None, None, dtoken
-
-
-def masked_row_tokens(x: torch.Tensor, mask: torch.Tensor, code: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
-    """Rows with ``mask`` replaced by ``token[code]`` (x [M, D], code int32 [M] in [0, R), token [R, D], R <= 32)."""
-    return _MaskedRowTokens.apply(x, mask, code, token)
-
-
-class _ExpandRowsTokens(torch.autograd.Function):
-    """Packed rows back on the full [T, N] node set: node (t, n) takes ``token[t]`` where ``mask[t, n]`` and packed
-    row ``new_id[t * N + n]`` elsewhere (``models/local_encoder.py:230`` applied to a stage that was evaluated for
-    the unmasked nodes only)."""
-
-    @staticmethod
-    def forward(ctx, x, rows, new_id, live, mask, token):
-        t, n = mask.shape
-        mask = mask.contiguous()
-        out = torch.where(mask.unsqueeze(-1), token.unsqueeze(1), x.index_select(0, new_id).view(t, n, -1))
-        ctx.save_for_backward(rows, live, mask)
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        rows, live, mask = ctx.saved_tensors
-        t, n, d = dy.shape
-        dy = dy.contiguous().view(t * n, d)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.where(live.unsqueeze(-1), dy.index_select(0, rows),
-                             torch.zeros((), dtype=dy.dtype, device=dy.device))
-        dtoken = None
-        if ctx.needs_input_grad[5]:
-            codes = torch.where(mask.reshape(-1), _codes(t, n, dy.device), -1)
-            dtoken = _rowsum_by_code(dy, codes, t)
-        return dx, None, None, None, None, dtoken
-
-
-def expand_rows_with_tokens(x: torch.Tensor, subset: RowSubset, mask: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
-    """[T, N, D] from packed rows ``x`` [capacity, D] of ``subset`` (the nodes with ``~mask``) and one token row per
-    step for the masked nodes; mask [T, N] bool, token [T, D]."""
-    if subset.num_rows != mask.numel() or x.shape[0] != subset.capacity:
-        raise ValueError("expand_rows_with_tokens: the subset does not belong to this node set")
-    return _ExpandRowsTokens.apply(x, subset.rows, subset.new_id, subset.live, mask, token)
-
-
-def step_guards(nan_check: Optional[torch.Tensor], finite_check: Optional[torch.Tensor],
-                extra: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """0-d device bool: ``nan_check`` holds a NaN, ``finite_check`` a NaN or an infinity, or ``extra`` (a
-    device bool) is set -- the step's guards (``models/hivt.py:264,272,294``) in three small launches and
-    without a multi-block framework reduction."""
-    ref = nan_check if nan_check is not None else finite_check
-    _need_gpu(ref)
-    a = nan_check.contiguous() if nan_check is not None else None
-    b = finite_check.contiguous() if finite_check is not None else None
-    for t in (a, b):
-        if t is not None and t.dtype != torch.float32:
-            raise TypeError("step_guards checks float32 tensors")
-    ex = extra.view(torch.uint8) if (extra is not None and extra.dtype == torch.bool) else extra
-    flag = torch.empty(1, dtype=torch.int32, device=ref.device)
-    _lib.call("hivt_step_guards", _p(a), a.numel() if a is not None else 0, _p(b), b.numel() if b is not None else 0,
-              _p(ex), _p(flag), _stream(ref))
-    return flag.view(torch.bool)[0]
-
-
-# --------------------------------------------------------------------------------------------
-# Row bookkeeping of a batch in single launches (hivt_gan_amd/csrc/rows.hip)
-# --------------------------------------------------------------------------------------------
-def _u8(t: torch.Tensor) -> torch.Tensor:
-    """A bool / uint8 tensor as uint8 whose last dimension is contiguous (a column slice of a 2-D mask stays a view:
-    the kernels take the row stride)."""
-    if not (t.dim() == 2 and t.stride(1) == 1):
-        t = t.contiguous()
-    return t.view(torch.uint8) if t.dtype == torch.bool else t
-
-
-_unit_scalars = {}
-
-
-def unit_scalar(ref: torch.Tensor) -> torch.Tensor:
-    """A cached 0-d float32 one on ``ref``'s device: the seed gradient of a backward pass (``loss.backward(unit)``)
-    without the fill that ``backward()`` issues for it on every call."""
-    key = str(ref.device)
-    t = _unit_scalars.get(key)
-    if t is None:
-        t = _unit_scalars[key] = torch.ones((), dtype=torch.float32, device=ref.device)
-    return t
-
-
-def batch_prepare_supported(data, historical_steps: int) -> bool:
-    """Whether ``batch_prepare`` applies: a GPU batch with the reference's tensor types."""
-    x = data.get("x")
-    if x is None or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or x.shape[2] != 2:
-        return False
-    pm = data.get("padding_mask")
-    if pm is None or pm.dtype not in (torch.bool, torch.uint8) or pm.shape[1] < historical_steps:
-        return False
-    for key in ("is_intersections", "turn_directions", "traffic_controls"):
-        t = data.get(key)
-        if t is None or t.dtype not in (torch.uint8, torch.bool):
-            return False
-    return data.get("rotate_angles") is not None and x.shape[1] >= historical_steps
-
-
-def batch_prepare(data, historical_steps: int) -> dict:
-    """Everything the step derives from the raw batch before the first layer, in one launch: ``rotate_mat``
-    [N, 2, 2], the targets rotated into the agents' frames (``y``, or None), ``x_rot`` [T * N, 2] (step-major rotated
-    displacements; ``x_steps``: the un-rotated ones in the same order), ``lane_code`` int32 [L] and ``keep_w`` [N] (1
-    where an agent has a valid future step)."""
-    x = data["x"]
-    n = int(x.shape[0])
-    T = int(historical_steps)
-    dev = x.device
-    pm = _u8(data["padding_mask"])
-    hf = int(pm.shape[1]) - T
-    y = data.get("y")
-    if y is not None:
-        if y.dtype != torch.float32 or tuple(y.shape) != (n, hf, 2):
-            raise ValueError(f"y must be float32 [N, {hf}, 2], got {y.dtype} {tuple(y.shape)}")
-        y = y.contiguous()
-    ang = data["rotate_angles"].contiguous()
-    if ang.dtype != torch.float32 or ang.shape != (n,):
-        raise ValueError("rotate_angles must be float32 [N]")
-    if x.stride(2) != 1:
-        x = x.contiguous()
-    lanes = [_u8(data[k]) for k in ("is_intersections", "turn_directions", "traffic_controls")]
-    num_lanes = int(lanes[0].shape[0])
-    rot = torch.empty(n, 2, 2, dtype=torch.float32, device=dev)
-    y_rot = torch.empty(n, hf, 2, dtype=torch.float32, device=dev) if y is not None else None
-    x_rot = torch.empty(T * n, 2, dtype=torch.float32, device=dev)
-    x_steps = torch.empty(T * n, 2, dtype=torch.float32, device=dev)
-    lane_code = torch.empty(num_lanes, dtype=torch.int32, device=dev)
-    keep_w = torch.empty(n, dtype=torch.float32, device=dev)
-    _lib.call("hivt_batch_prepare", _p(ang), _p(y), _p(x), x.stride(0), x.stride(1), _p(pm), pm.stride(0), _p(lanes[0]),
-              _p(lanes[1]), _p(lanes[2]), n, T, hf, num_lanes, _p(rot), _p(y_rot), _p(x_rot), _p(x_steps), _p(lane_code),
-              _p(keep_w), _stream(x))
-    return {"rotate_mat": rot, "y": y_rot, "x_rot": x_rot, "x_steps": x_steps, "lane_code": lane_code, "keep_w": keep_w}
-
-
-def row_subset_fixed(padding_mask: torch.Tensor, steps: int, capacity: int, rowptr: Optional[torch.Tensor],
-                     edge_counts=(), edge_caps=()) -> RowSubset:
-    """``row_subset`` of the (step, agent) nodes with ``~padding_mask[:, :steps]`` at a fixed capacity, in two
-    launches and without a read-back; ``overflow`` also covers the given device edge counters against their
-    capacities (the flag a fixed-capacity step discards its batch by)."""
-    _need_gpu(padding_mask)
-    pm = _u8(padding_mask)
-    n = int(pm.shape[0])
-    dev = pm.device
-    capacity = max(int(capacity), 1)
-    m = n * int(steps)
-    rows = torch.empty(capacity, dtype=torch.int32, device=dev)
-    new_id = torch.empty(m, dtype=torch.int32, device=dev)
-    live = torch.empty(capacity, dtype=torch.bool, device=dev)
-    count = torch.empty(2, dtype=torch.int32, device=dev)
-    overflow = torch.empty(1, dtype=torch.bool, device=dev)
-    packed = torch.empty(capacity + 1, dtype=torch.int32, device=dev) if rowptr is not None else None
-    if rowptr is not None and (rowptr.dtype != torch.int32 or rowptr.shape[0] != m + 1):
-        raise ValueError("rowptr must be int32 with steps * N + 1 entries")
-    cnt = list(edge_counts) + [None] * (3 - len(edge_counts))
-    cap = [int(c) for c in edge_caps] + [0] * (3 - len(edge_caps))
-    ws = _workspace(_lib.query("hivt_row_subset_workspace_bytes", n, int(steps)), dev)
-    _lib.call("hivt_row_subset", _p(pm), pm.stride(0), n, int(steps), capacity, _p(rowptr), _p(cnt[0]), cap[0], _p(cnt[1]),
-              cap[1], _p(cnt[2]), cap[2], _p(rows), _p(new_id), _p(live), _p(count), _p(packed), _p(overflow), _p(ws),
-              ws.numel(), _stream(pm))
-    return RowSubset(rows, new_id, live, count[0], capacity, m, packed, overflow.view(()))
-
-
-def center_rows(x_rot: torch.Tensor, bos_mask: torch.Tensor, rows: torch.Tensor, n: int, steps: int
-                ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Per packed (step, agent) node: its rotated displacement [capacity, 2] and its begin-of-sequence code (the
-    step where ``bos_mask[agent, step]``, else -1)."""
-    bos = _u8(bos_mask)
-    cap = int(rows.shape[0])
-    xc = torch.empty(cap, 2, dtype=torch.float32, device=x_rot.device)
-    code = torch.empty(cap, dtype=torch.int32, device=x_rot.device)
-    _lib.call("hivt_center_rows", _p(x_rot), _p(bos), bos.stride(0), _p(rows), int(n), int(steps), cap, _p(xc), _p(code),
-              _stream(x_rot))
-    return xc, code
-
-
-class _RowsPutTokens(torch.autograd.Function):
-    """``where(code >= 0, token[code], x)`` for x [M, D], code int32 [M] (-1: keep the row), token [R <= 32, D]."""
-
-    @staticmethod
-    def forward(ctx, x, code, token):
-        _need_gpu(x, code, token)
-        x2 = _rows(x)
-        m, d = x2.shape
-        token_c = token.contiguous()
-        out = torch.empty(m, d, dtype=torch.float32, device=x.device)
-        _lib.call("hivt_rows_put_tokens", _p(x2), x2.stride(0), _p(code), _p(token_c), m, d, 0, _p(out), _stream(x))
-        ctx.save_for_backward(code)
-        ctx.codes = int(token.shape[0])
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        (code,) = ctx.saved_tensors
-        dy = _rows(dy)
-        m, d = dy.shape
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(m, d, dtype=torch.float32, device=dy.device)
-            _lib.call("hivt_rows_put_tokens", _p(dy), dy.stride(0), _p(code), None, m, d, 0, _p(dx), _stream(dy))
-        dtoken = _rowsum_by_code(dy, code, ctx.codes) if ctx.needs_input_grad[2] else None
-        return dx, None, dtoken
-
-
-def rows_put_tokens(x: torch.Tensor, code: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
-    """Rows whose ``code`` is non-negative replaced by ``token[code]`` (one launch; the token's gradient is a
-    per-code row sum in a fixed order)."""
-    if x.shape[-1] % 4 != 0 or token.shape[0] > 32:
-        raise _unsupported(f"token rows of width {x.shape[-1]} over {token.shape[0]} codes")
-    return _RowsPutTokens.apply(x, code, token)
-
-
-class _TemporalInput(torch.autograd.Function):
-    """Input of the temporal encoder, ``models/local_encoder.py:230-232``: for step s < T row (s, n) is the padding
-    token of step s where ``padding_mask[n, s]``, else the agent-agent stage's row (packed rows looked up through
-    ``new_id``), row (T, n) the class token; the positional row of the step is added to all of them."""
-
-    @staticmethod
-    def forward(ctx, x, new_id, rows, count, padding_mask, pad_token, cls_token, pos_embed):
-        _need_gpu(x, padding_mask, pad_token)
-        pm = _u8(padding_mask)
-        n = int(pm.shape[0])
-        steps, d = int(pad_token.shape[0]), int(pad_token.shape[1])
-        x2 = x.reshape(-1, d).contiguous()
-        pad_c, cls_c, pos_c = pad_token.contiguous(), cls_token.contiguous(), pos_embed.contiguous()
-        out = torch.empty(steps + 1, n, d, dtype=torch.float32, device=x.device)
-        pad_code = torch.empty((steps + 1) * n, dtype=torch.int32, device=x.device)
-        _lib.call("hivt_temporal_input_fwd", _p(x2), _p(new_id), _p(pm), pm.stride(0), _p(pad_c), _p(cls_c), _p(pos_c),
-                  steps, n, d, _p(out), _p(pad_code), _stream(x))
-        ctx.save_for_backward(rows, count, pad_code)
-        ctx.cfg = (steps, n, d, tuple(x.shape))
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        rows, count, pad_code = ctx.saved_tensors
-        steps, n, d, x_shape = ctx.cfg
-        dy2 = dy.contiguous().view((steps + 1) * n, d)
-        dev = dy2.device
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if rows is not None:
-                cap = int(rows.shape[0])
-                dx = torch.empty(cap, d, dtype=torch.float32, device=dev)
-                _lib.call("hivt_gather_live_rows", _p(dy2), _p(rows), _p(count), cap, d, _p(dx), _stream(dy2))
-            else:  # every (step, agent) row was an input row: the gradient is dy outside the padded rows
-                dx = torch.empty(steps * n, d, dtype=torch.float32, device=dev)
-                _lib.call("hivt_rows_put_tokens", _p(dy2), d, _p(pad_code), None, steps * n, d, 0, _p(dx), _stream(dy2))
-            dx = dx.view(x_shape)
-        dpad = _rowsum_by_code(dy2, pad_code, steps) if ctx.needs_input_grad[5] else None
-        dpos = dcls = None
-        if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
-            dpos = _rowsum_by_code(dy2, _codes(steps + 1, n, dev), steps + 1)
-            dcls = dpos[steps] if ctx.needs_input_grad[6] else None
-        return dx, None, None, None, None, dpad, dcls, dpos
-
-
-def temporal_input(x: torch.Tensor, subset: Optional[RowSubset], padding_mask: torch.Tensor, pad_token: torch.Tensor,
-                   cls_token: torch.Tensor, pos_embed: torch.Tensor) -> torch.Tensor:
-    """[T + 1, N, D] input of the temporal encoder in one launch.  ``x``: the agent-agent stage's rows, packed
-    ([subset.capacity, D]) with ``subset`` or all of them ([T, N, D]) without; ``padding_mask`` [N, >= T]; pad_token
-    [T, D], cls_token [D], pos_embed [T + 1, D]."""
-    if subset is not None:
-        if subset.num_rows != padding_mask.shape[0] * pad_token.shape[0] or x.shape[0] != subset.capacity:
-            raise ValueError("temporal_input: the subset does not belong to this node set")
-        return _TemporalInput.apply(x, subset.new_id, subset.rows, subset.count.view(1), padding_mask, pad_token,
-                                    cls_token, pos_embed)
-    return _TemporalInput.apply(x, None, None, None, padding_mask, pad_token, cls_token, pos_embed)
-
-
-class _CategoryTable(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, a, b, c):
-        _need_gpu(a, b, c)
-        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
-        d = int(a.shape[1])
-        out = torch.empty(a.shape[0] * b.shape[0] * c.shape[0], d, dtype=torch.float32, device=a.device)
-        _lib.call("hivt_category_table_fwd", _p(a), _p(b), _p(c), a.shape[0], b.shape[0], c.shape[0], d, _p(out),
-                  _stream(a))
-        ctx.sizes = (int(a.shape[0]), int(b.shape[0]), int(c.shape[0]), d)
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
-        na, nb, nc, d = ctx.sizes
-        g = g.contiguous()
-        da = torch.empty(na, d, dtype=torch.float32, device=g.device)
-        db = torch.empty(nb, d, dtype=torch.float32, device=g.device)
-        dc = torch.empty(nc, d, dtype=torch.float32, device=g.device)
-        _lib.call("hivt_category_table_bwd", _p(g), na, nb, nc, d, _p(da), _p(db), _p(dc), _stream(g))
-        return da, db, dc
-
-
-def category_table(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
-    """``[(a[i] + b[j]) + c[k]]`` for all (i, j, k), row ``(i * len(b) + j) * len(c) + k``: the summed categorical
-    embeddings of ``models/local_encoder.py:361-363`` as one small table (one launch, one for its gradient)."""
-    return _CategoryTable.apply(a, b, c)
-
-
-class _DecoderOutput(torch.autograd.Function):
-
-    @staticmethod
-    def forward(ctx, loc, raw, modes, agent_major, min_scale):
-        _need_gpu(loc, raw)
-        loc2, raw2 = _rows2(loc), _rows2(raw)
-        m, two_h = loc2.shape
-        h = two_h // 2
-        out = torch.empty(modes, m // modes, h, 4, dtype=torch.float32, device=loc.device)
-        f = modes if agent_major else 1
-        _lib.call("hivt_decoder_output_fwd", _p(loc2), loc2.stride(0), _p(raw2), raw2.stride(0), m, h, f, float(min_scale),
-                  _p(out), _stream(loc))
-        ctx.save_for_backward(raw2)
-        ctx.cfg = (m, h, f, float(min_scale), tuple(loc.shape), tuple(raw.shape))
-        return out
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
-        (raw2,) = ctx.saved_tensors
-        m, h, f, min_scale, loc_shape, raw_shape = ctx.cfg
-        g = g.contiguous()
-        d_loc = torch.empty(m, 2 * h, dtype=torch.float32, device=g.device)
-        d_raw = torch.empty(m, 2 * h, dtype=torch.float32, device=g.device)
-        _lib.call("hivt_decoder_output_bwd", _p(g), _p(raw2), raw2.stride(0), m, h, f, min_scale, _p(d_loc), _p(d_raw),
-                  _stream(g))
-        return d_loc.view(loc_shape), d_raw.view(raw_shape), None, None, None
-
-
-def decoder_output(loc: torch.Tensor, scale_raw: torch.Tensor, modes: int, agent_major: bool,
-                   min_scale: float = 0.05) -> torch.Tensor:
-    """``cat(loc, clamp(elu(scale_raw) + 1, min=min_scale))`` viewed [modes, N, H, 4] (``models/decoder.py:131-139``)
-    from the two heads' outputs [modes * N, 2 H]; ``agent_major``: their rows are ordered (agent, mode)."""
-    return _DecoderOutput.apply(loc, scale_raw, int(modes), bool(agent_major), float(min_scale))
-
-
-# --------------------------------------------------------------------------------------------
-# The adversarial objectives of all critic scales in single launches
-# --------------------------------------------------------------------------------------------
-class _HingeR1Multi(torch.autograd.Function):
-    """``out[0] = sum_k loss_k``, ``out[1 + 2k] = loss_k``, ``out[2 + 2k] = r1_k`` over K critic scales (inputs:
-    s_real_0, grad_norm2_0, s_fake_0, s_real_1, ...)."""
-
-    @staticmethod
-    def forward(ctx, w, count, lambda_r1, *rows):
-        scales = len(rows) // 3
-        rows = [t.contiguous() for t in rows]
-        _need_gpu(w, *rows)
-        b = rows[0].shape[0]
-        for t in rows:
-            if t.shape != (b,) or t.dtype != torch.float32:
-                raise ValueError("hinge_r1_multi: every score / gradient-norm vector must be float32 [B]")
-        w = w.contiguous()
-        out = torch.empty(2 + 2 * scales, dtype=torch.float32, device=w.device)
-        _lib.call("hivt_hinge_r1_multi_fwd", _ptr_array(rows[0::3]), _ptr_array(rows[1::3]), _ptr_array(rows[2::3]), scales,
-                  _p(w), _p(count), b, float(lambda_r1), _p(out), _stream(w))
-        # (the last element of `out` holds the number of kept rows, given or computed by the kernel)
-        ctx.save_for_backward(w, out, *rows[0::3], *rows[2::3])
-        ctx.cfg = (scales, float(lambda_r1))
-        total, logs = out[0], out[1:1 + 2 * scales]
-        ctx.mark_non_differentiable(logs)  # only the total is an objective
-        ctx.set_materialize_grads(False)
-        return total, logs
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g_total, _g_logs):
-        scales, lambda_r1 = ctx.cfg
-        w, out, *rest = ctx.saved_tensors
-        s_real, s_fake = rest[:scales], rest[scales:]
-        b = w.shape[0]
-        if g_total is None:
-            return (None,) * (3 + 3 * scales)
-        g_total = g_total.contiguous()
-        count = out[1 + 2 * scales:]
-        grads = torch.empty(3 * scales, b, dtype=torch.float32, device=w.device)
-        g_real = [grads[3 * k] for k in range(scales)]
-        g_norm2 = [grads[3 * k + 1] for k in range(scales)]
-        g_fake = [grads[3 * k + 2] for k in range(scales)]
-        _lib.call("hivt_hinge_r1_multi_bwd", _p(g_total), _ptr_array(list(s_real)), _ptr_array(list(s_fake)), scales, _p(w),
-                  _p(count), b, lambda_r1, _ptr_array(g_real), _ptr_array(g_norm2), _ptr_array(g_fake), _stream(w))
-        return (None, None, None, *[grads[i] for i in range(3 * scales)])
-
-
-def hinge_r1_multi(terms, w: torch.Tensor, count: Optional[torch.Tensor], lambda_r1: float
-                   ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``terms``: per critic scale ``(s_real, grad_norm2, s_fake)`` (at most four scales).  Returns ``(total,
-    logs)``: the critics' objective -- the sum over the scales, in order, of ``mean_w relu(1 - s_real) + mean_w
-    relu(1 + s_fake) + lambda_r1 * r1`` -- and per scale that term and its ``r1 = mean_w grad_norm2``
-    (``mean_w(v) = sum(w * v) / count``; ``logs[2k]``, ``logs[2k + 1]``, no gradient).  ``count`` None: the number of
-    kept rows ``max(sum(w), 1)`` is computed by the same launch."""
-    if not 1 <= len(terms) <= 4:
-        raise ValueError("hinge_r1_multi: one to four scales")
-    flat = [t for term in terms for t in term]
-    return _HingeR1Multi.apply(w, count, float(lambda_r1), *flat)
-
-
-class _GeneratorTotal(torch.autograd.Function):
-    """``out[0] = (losses[0] + losses[1]) + out[1]``, ``out[1] = lambda_adv * sum_k out[2 + k]``, ``out[2 + k] =
-    -mean_w scores_k``."""
-
-    @staticmethod
-    def forward(ctx, losses, w, count, lambda_adv, *scores):
-        scales = len(scores)
-        scores = [t.contiguous() for t in scores]
-        _need_gpu(losses, w, *scores)
-        losses, w = losses.contiguous(), w.contiguous()
-        b = w.shape[0]
-        out = torch.empty(3 + scales, dtype=torch.float32, device=w.device)
-        _lib.call("hivt_generator_total_fwd", _p(losses), _ptr_array(scores), scales, _p(w), _p(count), b,
-                  float(lambda_adv), _p(out), _stream(w))
-        ctx.save_for_backward(w, out)
-        ctx.cfg = (scales, float(lambda_adv))
-        total, parts = out[0], out[1:2 + scales]
-        ctx.mark_non_differentiable(parts)
-        ctx.set_materialize_grads(False)
-        return total, parts
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g_total, _g_parts):
-        scales, lambda_adv = ctx.cfg
-        w, out = ctx.saved_tensors
-        b = w.shape[0]
-        if g_total is None:
-            return (None,) * (4 + scales)
-        g_total = g_total.contiguous()
-        count = out[2 + scales:]
-        g_losses = torch.empty(2, dtype=torch.float32, device=w.device)
-        g_s = torch.empty(scales, b, dtype=torch.float32, device=w.device)
-        _lib.call("hivt_generator_total_bwd", _p(g_total), scales, _p(w), _p(count), b, lambda_adv, _p(g_losses),
-                  _ptr_array([g_s[k] for k in range(scales)]), _stream(w))
-        return (g_losses, None, None, None, *[g_s[k] for k in range(scales)])
-
-
-def generator_total(losses: torch.Tensor, scores, w: torch.Tensor, count: Optional[torch.Tensor], lambda_adv: float
-                    ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """The generator's objective and its parts in one launch: ``(total, parts)`` with ``total = (reg_loss + cls_loss) +
-    g_adv`` for ``losses = (reg_loss, cls_loss)``, ``parts[0] = g_adv = lambda_adv * sum_k g_k`` and ``parts[1 + k] =
-    g_k = -mean_w scores_k`` per critic scale (``models/hivt.py:317-324``; the parts carry no gradient).  ``count``
-    None: ``max(sum(w), 1)``, computed by the same launch."""
-    if not 1 <= len(scores) <= 4:
-        raise ValueError("generator_total: one to four scales")
-    return _GeneratorTotal.apply(losses, w, count, float(lambda_adv), *scores)
 
 
 # --------------------------------------------------------------------------------------------
