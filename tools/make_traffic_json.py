@@ -28,7 +28,7 @@ def caller(rows, split, wpn, unroll):
 out = {}
 for name, scale in (("pmc_fetch_size.csv", 2 * 1024.0), ("pmc_write_size.csv", 1024.0)):
     for r in csv.DictReader(open(f"{src}/{name}")):
-        m = re.search(r"seg_attn_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?(?:, (?:true|false))?>", r["kernel"])
+        m = re.search(r"seg_attn_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (\w+), (\w+)(?:, (\d+))?(?:, (?:true|false)){0,2}>", r["kernel"])
         if not m:
             continue
         kind, _d, _lph, wpn, glob, split, unroll = m.groups()
