@@ -43,6 +43,7 @@ SIGNATURES = {
                                         _P, c_int64, c_int32, c_int, _P, _P, _P]),
     "hivt_stack_pairs": (c_int, [_P, c_int32, _P]),
     "hivt_segment_sum_rows": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
+    "hivt_segment_sum_rows_half": (c_int, [_P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P]),
     "hivt_gated_update_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P]),
     "hivt_gated_update_bwd": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, _P,
                                       _P, _P, c_int64, _P, c_int64, _P]),

@@ -379,7 +379,9 @@ __global__ __launch_bounds__(256) void csr_row_sort_kernel(const int32_t* __rest
 }
 
 // ---- segment sum of rows --------------------------------------------------------------------
-// One wave per output row; lanes cover the row in float4 columns, several input rows in flight.
+// One wave per output row; lanes cover the row in groups of four columns, four input rows requested together and
+// added in ascending order.  HALF: the input rows hold bfloat16 values (row_stride counts them), widened exactly.
+template <bool HALF>
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __restrict__ rows, int64_t row_stride,
                                                                int32_t width, const int32_t* __restrict__ rowptr,
                                                                const int32_t* __restrict__ perm, int32_t num_rows,
@@ -388,11 +390,32 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float* __re
   if (row >= num_rows) return;
   const int lane = threadIdx.x & 63;
   const int beg = rowptr[row], end = rowptr[row + 1];
+  auto load = [&](int64_t r, int c) {
+    if constexpr (HALF) {
+      const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(rows) + r * row_stride + c);
+      return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                         __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+    } else {
+      return *reinterpret_cast<const float4*>(rows + r * row_stride + c);
+    }
+  };
   for (int c = lane * 4; c < width; c += kWave * 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = beg; i < end; ++i) {
-      const int64_t r = perm ? perm[i] : i;
-      const float4 v = *reinterpret_cast<const float4*>(rows + r * row_stride + c);
+    int i = beg;
+    for (; i + 4 <= end; i += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load(perm ? perm[i + u] : i + u, c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc.x += v[u].x;
+        acc.y += v[u].y;
+        acc.z += v[u].z;
+        acc.w += v[u].w;
+      }
+    }
+    for (; i < end; ++i) {
+      const float4 v = load(perm ? perm[i] : i, c);
       acc.x += v.x;
       acc.y += v.y;
       acc.z += v.z;
@@ -582,17 +605,38 @@ extern "C" int hivt_csr_build_static(const int32_t* key, int64_t E, const int32_
   return csr_build_launch(what, key, E, count, num_rows, rowptr, perm, base, base + HIVT_CSR_STATIC_MAX_ROWS, stream);
 }
 
-extern "C" int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
-                                     const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
-                                     hivt_stream_t stream) {
-  const char* what = "hivt_segment_sum_rows";
+static int segment_sum_rows_impl(const char* what, const void* rows, int64_t row_stride, int32_t width,
+                                 const int32_t* rowptr, const int32_t* perm, int32_t num_rows, float* out,
+                                 int64_t out_stride, bool half, hivt_stream_t stream) {
   HIVT_REQUIRE(width > 0 && width % 4 == 0 && row_stride % 4 == 0 && out_stride % 4 == 0, HIVT_ERR_ARG,
-               "%s: width and strides must be multiples of 4 floats", what);
+               "%s: width and strides must be multiples of 4 elements", what);
   HIVT_REQUIRE(num_rows >= 0, HIVT_ERR_ARG, "%s: negative row count", what);
   if (num_rows == 0) return HIVT_OK;
   HIVT_REQUIRE(rows && rowptr && out, HIVT_ERR_ARG, "%s: null pointer", what);
-  hipLaunchKernelGGL(segment_sum_rows_kernel, dim3((unsigned)((num_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     rows, row_stride, width, rowptr, perm, num_rows, out, out_stride);
+  HIVT_REQUIRE((reinterpret_cast<uintptr_t>(rows) & (half ? 7 : 15)) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               HIVT_ERR_ARG, "%s: rows and out must be aligned for four-element accesses", what);
+  const dim3 grid((unsigned)((num_rows + 3) / 4));
+  const float* r = reinterpret_cast<const float*>(rows);
+  if (half)
+    hipLaunchKernelGGL(segment_sum_rows_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, r, row_stride, width,
+                       rowptr, perm, num_rows, out, out_stride);
+  else
+    hipLaunchKernelGGL(segment_sum_rows_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, r, row_stride, width,
+                       rowptr, perm, num_rows, out, out_stride);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
+                                     const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
+                                     hivt_stream_t stream) {
+  return segment_sum_rows_impl("hivt_segment_sum_rows", rows, row_stride, width, rowptr, perm, num_rows, out, out_stride,
+                               false, stream);
+}
+
+extern "C" int hivt_segment_sum_rows_half(const void* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
+                                          const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
+                                          hivt_stream_t stream) {
+  return segment_sum_rows_impl("hivt_segment_sum_rows_half", rows, row_stride, width, rowptr, perm, num_rows, out,
+                               out_stride, true, stream);
 }

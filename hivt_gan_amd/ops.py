@@ -720,8 +720,8 @@ class _PairLinear(torch.autograd.Function):
         n = w.shape[0]
         dev = x2.device
         half = dy.dtype == torch.bfloat16  # handed over by _EdgeAttention, never by autograd
-        if half and (dy.shape != (m, n) or not dy.is_contiguous() or (table_rows and ctx.needs_input_grad[5])):
-            raise RuntimeError("a bfloat16 gradient must be a contiguous [rows, n_a + n_b] tensor of a layer without table rows")
+        if half and (dy.shape != (m, n) or not dy.is_contiguous()):
+            raise RuntimeError("a bfloat16 gradient must be a contiguous [rows, n_a + n_b] tensor")
         dy2 = dy if half else _rows2(dy)
         s = _stream(x2)
         dx = None
@@ -742,8 +742,8 @@ class _PairLinear(torch.autograd.Function):
             d_table = getattr(ctx, "d_table_out", None)  # (a caller that runs this node itself may say where it goes)
             if d_table is None:
                 d_table = torch.empty(table_rows, n, dtype=torch.float32, device=dev)
-            _lib.call("hivt_segment_sum_rows", _p(dy2), dy2.stride(0), n, _p(rowptr_by_index), _p(perm_by_index),
-                      table_rows, _p(d_table), _ld(d_table), s)
+            _lib.call("hivt_segment_sum_rows_half" if half else "hivt_segment_sum_rows", _p(dy2), dy2.stride(0), n,
+                      _p(rowptr_by_index), _p(perm_by_index), table_rows, _p(d_table), _ld(d_table), s)
         return dx, dw[:n_a], db[:n_a], dw[n_a:], db[n_a:], d_table, None, None, None
 
 
@@ -1864,7 +1864,7 @@ class _AttentionBlock(torch.autograd.Function):
         proj.saved_tensors, proj.cfg, proj.param_leaves = saved[ctx.split[0]:ctx.split[1]], proj_cfg, leaves
         x2, w_kv = proj.saved_tensors[0], proj.saved_tensors[1]
         attn.dq_out = da[:, :d]
-        attn.dkv_half = (not node_terms and _half_gradients() and x2.shape[1] % 4 == 0 and w_kv.shape[0] % 8 == 0
+        attn.dkv_half = (_half_gradients() and x2.shape[1] % 4 == 0 and w_kv.shape[0] % 8 == 0
                          and x2.stride(0) % 4 == 0 and w_kv.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0
                          and w_kv.data_ptr() % 16 == 0)
         dkv = _SegAttn.backward(attn, d_agg)[1]

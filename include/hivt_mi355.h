@@ -334,6 +334,13 @@ int hivt_segment_sum_rows(const float* rows, int64_t row_stride, int32_t width, 
                           const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
                           hivt_stream_t stream);
 
+/* hivt_segment_sum_rows for input rows of bfloat16 values (row_stride counts them; rows on 8-byte boundaries), summed
+ * in fp32: the per-source sums of a dK | dV gradient that hivt_seg_attn_bwd wrote under HIVT_DKV_BF16
+ * (models/global_interactor.py:116,118). */
+int hivt_segment_sum_rows_half(const void* rows, int64_t row_stride, int32_t width, const int32_t* rowptr,
+                               const int32_t* perm, int32_t num_rows, float* out, int64_t out_stride,
+                               hivt_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Gated update (elementwise tail of update())
  * ------------------------------------------------------------------------------------------ */

@@ -74,8 +74,14 @@ def test_attention_block_equals_its_separate_nodes(node_terms, precision):
         ops.set_matmul_precision(prev)
     assert torch.equal(y_a, y_b)
     # the centre rows' gradient is one reduction over all projections instead of a sum of rounded products
-    tol = 2e-6 if precision == "fp32" else 2e-3
+    # (bf16 mode: the block keeps dK | dV as bfloat16 rows, which the separate nodes of the interaction layout do not)
+    tol = 2e-6 if precision == "fp32" else (1e-2 if node_terms else 2e-3)
     for k in g_a:
+        if k in ("k.b", "k_node.b") and precision == "bf16":
+            # exactly zero in exact arithmetic (the softmax does not change when every key of a row moves by the same
+            # vector): what the two runs hold is rounding residue, compared with the weight gradient's size instead
+            assert float(g_b[k].norm()) <= 1e-2 * float(g_b[k[:-1] + "w"].norm())
+            continue
         err = float((g_a[k] - g_b[k]).norm() / g_a[k].norm().clamp_min(1e-30))
         assert err <= (tol if k == "center" else 1e-6 if precision == "fp32" else tol), (k, err)
 
@@ -95,3 +101,28 @@ def test_attention_block_dropout_and_padding_run_and_stay_finite():
     y.sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(c.grad).all() and torch.isfinite(x.grad).all()
     assert float(x.grad[e - 500:].abs().max()) == 0.0  # padded edge rows receive exact zeros
+
+
+def test_segment_sum_of_bfloat16_rows_equals_the_sum_of_the_widened_rows():
+    from hivt_gan_amd import _lib
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(7)
+    n, e, width = 300, 5000, 256
+    rows = torch.randn(e, width, generator=gen).to(dev).to(torch.bfloat16)
+    src = torch.randint(0, n, (e,), generator=gen)
+    order = torch.sort(src, stable=True)
+    perm = order.indices.to(torch.int32).to(dev)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.bincount(src, minlength=n).cumsum(0)
+    rowptr = rowptr.to(torch.int32).to(dev)
+    wide = rows.float()
+    out_h = torch.empty(n, width, device=dev)
+    out_f = torch.empty(n, width, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("hivt_segment_sum_rows_half", rows.data_ptr(), width, width, rowptr.data_ptr(), perm.data_ptr(), n,
+              out_h.data_ptr(), width, st)
+    _lib.call("hivt_segment_sum_rows", wide.data_ptr(), width, width, rowptr.data_ptr(), perm.data_ptr(), n,
+              out_f.data_ptr(), width, st)
+    assert torch.equal(out_h, out_f)
+    ref = torch.zeros(n, width, dtype=torch.float64, device=dev).index_add_(0, src.to(dev), wide.double())
+    assert float((out_f.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
