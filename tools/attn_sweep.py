@@ -36,6 +36,12 @@ def main():
     ap.add_argument("--no-node-terms", action="store_true",
                     help="time the interaction set without the per-source node rows (what the in-kernel gathers cost)")
     ap.add_argument("--only", default=None, help="time only this edge set (agent-agent, lane-actor, interaction)")
+    ap.add_argument("--uniform", action="store_true",
+                    help="replace every edge set's row lengths by equal ones (same rows, same edges): what the spread "
+                         "of the row lengths costs")
+    ap.add_argument("--shuffled", action="store_true", help="the same row lengths in a random order")
+    ap.add_argument("--sorted", action="store_true",
+                    help="rows in descending order of length (same multiset of lengths): what the ORDER of the rows costs")
     ap.add_argument("--half-grads", action="store_true",
                     help="backward writes dK | dV as bfloat16 rows (sets without node terms only)")
     args = ap.parse_args()
@@ -56,6 +62,19 @@ def main():
         if args.only is not None and tag != args.only:
             continue
         n, e = es.num_dst, es.num_edges
+        if args.uniform or args.sorted or args.shuffled:
+            deg = (es.rowptr[1:] - es.rowptr[:-1]).cpu().long()
+            if args.uniform:
+                base, extra = divmod(int(deg.sum()), n)
+                deg = torch.full((n,), base, dtype=torch.long)
+                deg[:extra] += 1
+            elif args.shuffled:
+                deg = deg[torch.randperm(n, generator=torch.Generator().manual_seed(1))]
+            else:
+                deg = torch.sort(deg, descending=True).values
+            rowptr = torch.zeros(n + 1, dtype=torch.long)
+            rowptr[1:] = deg.cumsum(0)
+            es.rowptr = rowptr.to(torch.int32).to(dev)
         rp = es.rowptr.cpu()
         live = int((rp[1:] > rp[:-1]).sum())
         embed = torch.randn(e, D, device=dev)
