@@ -26,19 +26,19 @@ SIGNATURES = {
     "hivt_edges_all_pairs_csr": (c_int, [_P, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_float,
                                          c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hivt_csr_build": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P, c_size_t, _P]),
+    "hivt_csr_build": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "hivt_csr_build_static": (c_int, [_P, c_int64, _P, c_int32, _P, _P, _P]),
     "hivt_edge_gather_rotate_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "hivt_edge_gather_rotate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
     "hivt_edge_relpose_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
-    "hivt_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64, c_int32,
+    "hivt_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int32, c_int64, c_int32,
                                   c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P]),
-    "hivt_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32,
+    "hivt_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int32,
                                   c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, c_int64, _P, _P, c_int64,
                                   c_int32, c_int, _P]),
-    "hivt_seg_attn_fwd_timed": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int32, c_int64,
+    "hivt_seg_attn_fwd_timed": (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int32, c_int64,
                                         c_int32, c_int32, c_float, c_uint64, _P, _P, _P, _P, c_int, _P, _P, _P]),
-    "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P,
+    "hivt_seg_attn_bwd_timed": (c_int, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P,
                                         c_int32, c_int64, c_int32, c_int32, c_float, c_uint64, _P, _P, c_int64, _P,
                                         _P, c_int64, c_int32, c_int, _P, _P, _P]),
     "hivt_stack_pairs": (c_int, [_P, c_int32, _P]),

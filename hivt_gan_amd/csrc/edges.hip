@@ -127,6 +127,56 @@ __global__ __launch_bounds__(1024) void scan_single_block_kernel(const int32_t* 
   if (tid == 1023 && total_out != nullptr) *total_out = part[1023];
 }
 
+// The same scan for the row lengths of a CSR build, followed by a ranking of the rows by length, longest first
+// (`order` [n]: a permutation of the rows; rows of one length class in no particular order).  A kernel that gives
+// every row a workgroup and walks the rows in this order starts its long rows first, so that the launch does not
+// end on a few of them (the order changes nothing but the schedule).  Classes of two lengths, 512 of them.
+constexpr int kLengthClasses = 512;
+__global__ __launch_bounds__(1024) void scan_rank_single_block_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                      int32_t* __restrict__ out,
+                                                                      int32_t* __restrict__ total_out,
+                                                                      int32_t* __restrict__ order) {
+  __shared__ int part[1024];
+  __shared__ int cls[kLengthClasses];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  auto class_of = [](int len) { return kLengthClasses - 1 - min(len >> 1, kLengthClasses - 1); };  // longest = class 0
+  for (int c = tid; c < kLengthClasses; c += 1024) cls[c] = 0;
+  int s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += in[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int64_t i = lo; i < hi; ++i) atomicAdd(&cls[class_of(in[i])], 1);
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid == 0 ? 0 : part[tid - 1];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == 1023 && total_out != nullptr) *total_out = part[1023];
+  __syncthreads();
+  // exclusive scan of the class counts (part is free again), then every row takes the next slot of its class
+  if (tid < kLengthClasses) part[tid] = cls[tid];
+  __syncthreads();
+  for (int o = 1; o < kLengthClasses; o <<= 1) {
+    int v = (tid < kLengthClasses && tid >= o) ? part[tid - o] : 0;
+    __syncthreads();
+    if (tid < kLengthClasses) part[tid] += v;
+    __syncthreads();
+  }
+  if (tid < kLengthClasses) cls[tid] = part[tid] - cls[tid];  // first slot of the class
+  __syncthreads();
+  for (int64_t i = lo; i < hi; ++i) order[atomicAdd(&cls[class_of(in[i])], 1)] = (int32_t)i;
+}
+
 template <class Pred>
 __global__ __launch_bounds__(kFilterThreads) void filter_write_kernel(Pred pred, int64_t items,
                                                                       const int32_t* __restrict__ tile_offsets,
@@ -524,7 +574,8 @@ extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {
 // Launch sequence shared by hivt_csr_build and hivt_csr_build_static: `cursor` (num_rows words) and `tmp`
 // (E words) are the scratch the kernels need; both are fully (re)initialised here before use.
 static int csr_build_launch(const char* what, const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
-                            int32_t* rowptr, int32_t* perm, int32_t* cursor, int32_t* tmp, hipStream_t stream) {
+                            int32_t* rowptr, int32_t* perm, int32_t* cursor, int32_t* tmp, hipStream_t stream,
+                            int32_t* row_order = nullptr) {
   // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
   zero_words(cursor, num_rows > 0 ? num_rows : 1, stream);
   HIVT_CHECK_LAUNCH(what);
@@ -533,8 +584,12 @@ static int csr_build_launch(const char* what, const int32_t* key, int64_t E, con
                        cursor);
     HIVT_CHECK_LAUNCH(what);
   }
-  hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, cursor, (int64_t)num_rows, rowptr,
-                     rowptr + num_rows);
+  if (row_order != nullptr && num_rows > 0)
+    hipLaunchKernelGGL(scan_rank_single_block_kernel, dim3(1), dim3(1024), 0, stream, cursor, (int64_t)num_rows, rowptr,
+                       rowptr + num_rows, row_order);
+  else
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(1024), 0, stream, cursor, (int64_t)num_rows, rowptr,
+                       rowptr + num_rows);
   HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
     zero_words(cursor, num_rows, stream);
@@ -550,8 +605,8 @@ static int csr_build_launch(const char* what, const int32_t* key, int64_t E, con
 }
 
 extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
-                              int32_t* rowptr, int32_t* perm, void* workspace, size_t workspace_bytes,
-                              hivt_stream_t stream_) {
+                              int32_t* rowptr, int32_t* perm, int32_t* row_order, void* workspace,
+                              size_t workspace_bytes, hivt_stream_t stream_) {
   const char* what = "hivt_csr_build";
   hipStream_t stream = (hipStream_t)stream_;
   HIVT_REQUIRE(E >= 0 && E < (int64_t)1 << 31 && num_rows >= 0, HIVT_ERR_ARG, "%s: bad sizes", what);
@@ -562,7 +617,7 @@ extern "C" int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* coun
   int32_t* cursor = reinterpret_cast<int32_t*>(workspace);
   int32_t* tmp = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) +
                                             align_up((size_t)(num_rows > 0 ? num_rows : 1) * sizeof(int32_t), 256));
-  return csr_build_launch(what, key, E, count, num_rows, rowptr, perm, cursor, tmp, stream);
+  return csr_build_launch(what, key, E, count, num_rows, rowptr, perm, cursor, tmp, stream, row_order);
 }
 
 // ---- the entry point that allocates nothing ---------------------------------------------------

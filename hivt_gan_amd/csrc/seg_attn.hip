@@ -33,6 +33,7 @@ struct SegAttnArgs {
   int64_t node_stride;
   const int32_t* src;
   const int32_t* rowptr;
+  const int32_t* row_order;  // optional [N]: the row that the g-th row group of the launch serves (one row per group)
   int32_t N;
   int32_t H;
   // 0: edge e of the CSR order is row e of k / v / dk / dv.  Otherwise the rows of a target are interleaved
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const SegAttnArgs a) 
   const int c = lane % LPR;
   const int h = c / LPH;
   const int win = wave % WPN;
-  const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  if (!SPLIT && a.row_order != nullptr && n < a.N) n = a.row_order[n];
   if (!SPLIT && WPN == 1 && n >= a.N) return;  // with WPN > 1 every wave stays for the barrier (row_ok gates the work)
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const SegAttnArgs a) 
   const int c = lane % LPR;
   const int h = c / LPH;
   const int win = wave % WPN;
-  const int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  int n = (blockIdx.x * NPB + wave / WPN) * RPW + (SPLIT ? sub : 0);
+  if (!SPLIT && a.row_order != nullptr && n < a.N) n = a.row_order[n];
   if (!SPLIT && WPN == 1 && n >= a.N) return;
   const bool row_ok = n < a.N;
   const int nc = row_ok ? n : a.N - 1;
@@ -597,8 +600,8 @@ using namespace hivt;
 
 static int seg_attn_fwd_impl(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                              const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                             int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                             const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                             const int32_t* row_order, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                             uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
                              hivt_stream_t stream, void* ev_start, void* ev_stop) {
   const char* what = "hivt_seg_attn_fwd";
   HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
@@ -615,7 +618,7 @@ static int seg_attn_fwd_impl(const float* q, int64_t q_stride, const float* k, c
   SegAttnArgs a{};
   a.q = q; a.q_stride = q_stride; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
-  a.rowptr = rowptr; a.N = N; a.H = H;
+  a.rowptr = rowptr; a.row_order = row_order; a.N = N; a.H = H;
   if (dtype & HIVT_ROWS_INTERLEAVED) {
     HIVT_REQUIRE(!global && E % N == 0, HIVT_ERR_ARG,
                  "%s: interleaved rows need E a multiple of N and no node terms (E=%lld N=%d)", what, (long long)E, N);
@@ -634,30 +637,31 @@ static int seg_attn_fwd_impl(const float* q, int64_t q_stride, const float* k, c
 
 extern "C" int hivt_seg_attn_fwd(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                                  const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
-                                 const int32_t* rowptr, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
-                                 uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out,
-                                 int dtype, hivt_stream_t stream) {
-  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H,
+                                 const int32_t* rowptr, const int32_t* row_order, int32_t N, int64_t E, int32_t D,
+                                 int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr, float* out,
+                                 float* m_out, float* den_out, int dtype, hivt_stream_t stream) {
+  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, row_order, N, E, D, H,
                            dropout_p, seed, seed_ptr, out, m_out, den_out, dtype, stream, nullptr, nullptr);
 }
 
 extern "C" int hivt_seg_attn_fwd_timed(const float* q, int64_t q_stride, const float* k, const float* v,
                                        int64_t kv_stride, const float* k_node, const float* v_node,
-                                       int64_t node_stride, const int32_t* src, const int32_t* rowptr, int32_t N,
-                                       int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                                       const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
-                                       hivt_stream_t stream, void* start_event, void* stop_event) {
-  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, N, E, D, H,
+                                       int64_t node_stride, const int32_t* src, const int32_t* rowptr,
+                                       const int32_t* row_order, int32_t N, int64_t E, int32_t D, int32_t H,
+                                       float dropout_p, uint64_t seed, const uint64_t* seed_ptr, float* out,
+                                       float* m_out, float* den_out, int dtype, hivt_stream_t stream,
+                                       void* start_event, void* stop_event) {
+  return seg_attn_fwd_impl(q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, row_order, N, E, D, H,
                            dropout_p, seed, seed_ptr, out, m_out, den_out, dtype, stream, start_event, stop_event);
 }
 
 static int seg_attn_bwd_impl(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                              const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
-                             const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                             int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                             const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
-                             int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream, void* ev_start,
-                             void* ev_stop) {
+                             const int32_t* rowptr, const int32_t* row_order, const float* out, const float* m,
+                             const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                             uint64_t seed, const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk,
+                             float* dv, int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream,
+                             void* ev_start, void* ev_stop) {
   const char* what = "hivt_seg_attn_bwd";
   HIVT_REQUIRE((ev_start == nullptr) == (ev_stop == nullptr), HIVT_ERR_ARG, "%s: need both events or none", what);
   int rc = check_shape(what, N, E, D, H, kv_stride, dtype, dropout_p);
@@ -676,7 +680,7 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, int64_t q_strid
   SegAttnArgs a{};
   a.q = q; a.q_stride = q_stride; a.dq_stride = dq_stride; a.k = k; a.v = v; a.kv_stride = kv_stride;
   a.k_node = k_node; a.v_node = v_node; a.node_stride = node_stride; a.src = src;
-  a.rowptr = rowptr; a.N = N; a.H = H;
+  a.rowptr = rowptr; a.row_order = row_order; a.N = N; a.H = H;
   if (dtype & HIVT_ROWS_INTERLEAVED) {
     HIVT_REQUIRE(!global && E % N == 0 && !zero_tail, HIVT_ERR_ARG,
                  "%s: interleaved rows need E a multiple of N, no node terms and no padding (E=%lld N=%d)", what,
@@ -704,11 +708,12 @@ static int seg_attn_bwd_impl(const float* d_out, const float* q, int64_t q_strid
 
 extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v,
                                  int64_t kv_stride, const float* k_node, const float* v_node, int64_t node_stride,
-                                 const int32_t* src, const int32_t* rowptr, const float* out, const float* m,
-                                 const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                                 const int32_t* src, const int32_t* rowptr, const int32_t* row_order,
+                                 const float* out, const float* m, const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
                                  uint64_t seed, const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk,
                                  float* dv, int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream) {
-  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den,
+  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, row_order,
+                           out, m, den,
                            N, E, D, H, dropout_p, seed, seed_ptr, dq, dq_stride, dk, dv, dkv_stride, zero_tail, dtype,
                            stream, nullptr, nullptr);
 }
@@ -716,12 +721,14 @@ extern "C" int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_s
 extern "C" int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, int64_t q_stride, const float* k,
                                        const float* v, int64_t kv_stride, const float* k_node, const float* v_node,
                                        int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                                       const float* out, const float* m, const float* den, int32_t N, int64_t E,
+                                       const int32_t* row_order, const float* out, const float* m, const float* den,
+                                       int32_t N, int64_t E,
                                        int32_t D, int32_t H, float dropout_p, uint64_t seed,
                                        const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
                                        int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream,
                                        void* start_event, void* stop_event) {
-  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, out, m, den,
+  return seg_attn_bwd_impl(d_out, q, q_stride, k, v, kv_stride, k_node, v_node, node_stride, src, rowptr, row_order,
+                           out, m, den,
                            N, E, D, H, dropout_p, seed, seed_ptr, dq, dq_stride, dk, dv, dkv_stride, zero_tail, dtype,
                            stream, start_event, stop_event);
 }

@@ -113,6 +113,8 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
         valid = True if fused_rows else ~data["padding_mask"][:, :T].t().reshape(-1)
     # (read back with the edge counts when no capacities are given; a fixed-capacity plan never needs it)
     live_rows = valid.sum(dtype=torch.int32).view(1) if (valid is not None and caps is None) else None
+    # (of the three sets only the lane -> actor rows differ widely in length -- an agent near an intersection has
+    # several times the lane segments of one on a straight road -- so only that set asks for the ranking of its rows)
     la = ops.edges_radius(data["lane_actor_index"], data["lane_actor_vectors"], local_radius)
     row_cap = min(int(caps[3]), T * n) if (caps is not None and len(caps) > 3) else T * n
     if from_pairs:
@@ -124,7 +126,7 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
             counts = torch.cat([aa[4], la[3], gi[4]] + ([live_rows] if valid is not None else [])).cpu()
             c_aa, c_la, c_gi = (int(c) for c in counts[:3])
             sets = [EdgeSet(T * n, T * n, aa[1][:c_aa], aa[2][:c_aa], aa[3][:c_aa], aa[0], None, aa[1][:c_aa], aa[2][:c_aa]),
-                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n),
+                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, order=True),
                     EdgeSet(n, n, gi[1][:c_gi], gi[2][:c_gi], gi[3][:c_gi], gi[0], None, gi[1][:c_gi], gi[2][:c_gi])]
             rows = ops.row_subset(valid, None, sets[0].rowptr, int(counts[3])) if valid is not None else None
             return EdgePlan(*sets, aa_rows=rows)
@@ -134,13 +136,14 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
             # counts go down as they are; the packed agent-agent rows and the overflow flag of all four capacities
             # come out of one call
             sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4]),
-                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3]),
+                    ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3], order=True),
                     EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4])]
             rows = ops.row_subset_fixed(data["padding_mask"], T, row_cap, sets[0].rowptr, (aa[4], la[3], gi[4]),
                                         (pair_caps[0], c_la, pair_caps[1]))
             return EdgePlan(*sets, overflow=rows.overflow, counts=(aa[4], la[3], gi[4]), aa_rows=rows)
         sets = [EdgeSet(T * n, T * n, aa[1], aa[2], aa[3], aa[0], None, aa[1], aa[2], count=aa[4].clamp(max=pair_caps[0])),
-                ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3].clamp(max=c_la)),
+                ops.make_edge_set(la[0][:c_la], la[1][:c_la], la[2][:c_la], num_lanes, n, count=la[3].clamp(max=c_la),
+                                  order=True),
                 EdgeSet(n, n, gi[1], gi[2], gi[3], gi[0], None, gi[1], gi[2], count=gi[4].clamp(max=pair_caps[1]))]
         overflow = (aa[4] > pair_caps[0]) | (la[3] > c_la) | (gi[4] > pair_caps[1])
         return EdgePlan(*sets, overflow=overflow.view(()), counts=(aa[4], la[3], gi[4]), aa_rows=None)
@@ -150,14 +153,15 @@ def build_edge_plan(data, historical_steps: int, local_radius: Optional[float], 
     if caps is None:
         # the only host synchronisation of the forward pass
         counts = torch.cat([aa[3], la[3], gi[3]] + ([live_rows] if valid is not None else [])).cpu()
-        sets = [ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd)
+        sets = [ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd, order=lst is la)
                 for lst, c, (ns, nd) in zip((aa, la, gi), (int(c) for c in counts[:3]), shapes)]
         rows = ops.row_subset(valid, None, sets[0].rowptr, int(counts[3])) if valid is not None else None
         return EdgePlan(*sets, aa_rows=rows)
     caps = [min(int(c), int(lst[0].shape[0])) for c, lst in zip(caps, (aa, la, gi))]
     sets, overflow = [], None
     for lst, c, (ns, nd) in zip((aa, la, gi), caps, shapes):
-        sets.append(ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd, count=lst[3].clamp(max=c)))
+        sets.append(ops.make_edge_set(lst[0][:c], lst[1][:c], lst[2][:c], ns, nd, count=lst[3].clamp(max=c),
+                                      order=lst is la))
         over = lst[3] > c
         overflow = over if overflow is None else overflow | over
     rows = ops.row_subset(valid, row_cap, sets[0].rowptr) if valid is not None else None
@@ -235,21 +239,24 @@ class _EdgeAttentionBase(nn.Module):
         dropout for per-edge embeddings already in CSR order (``local_encoder.py:174-188,197-199`` /
         ``:364-379,391-394``)."""
         # `rowptr`: the edge set's row pointer re-indexed to packed target rows (`center` then holds those rows)
+        # (a set with widely spread row lengths brings the order its attention launches start their rows in)
+        order = edges.row_order if rowptr is None else None
         rowptr = edges.rowptr if rowptr is None else rowptr
         if ops.attention_block_supported(center, edge_embed, residual):
             return ops.attention_block(center, residual, edge_embed, rowptr, self.lin_q, self.lin_k, self.lin_v,
                                        self.lin_ih, self.lin_hh, self.lin_self, self.out_proj, self.num_heads,
                                        self.attn_drop.p, self.proj_drop.p, self.training, tag=type(self).__name__,
-                                       padded=edges.count is not None)
+                                       padded=edges.count is not None, row_order=order)
         q = _linear(center, self.lin_q)
         if edge_embed.is_cuda and edge_embed.dtype == torch.float32 and edge_embed.dim() == 2:
             # key | value projection and attention as one node: their shared gradient stays inside it
             agg = ops.edge_attention(q, edge_embed, self.lin_k, self.lin_v, rowptr, self.num_heads, self.attn_drop.p,
-                                     self.training, tag=type(self).__name__, padded=edges.count is not None)
+                                     self.training, tag=type(self).__name__, padded=edges.count is not None,
+                                     row_order=order)
         else:
             kv = _fused_linear(edge_embed, self.lin_k, self.lin_v)
             agg = ops.seg_attn(q, kv, rowptr, self.num_heads, self.attn_drop.p, self.training,
-                               tag=type(self).__name__, padded=edges.count is not None)
+                               tag=type(self).__name__, padded=edges.count is not None, row_order=order)
         if residual is not None:
             return ops.gated_update_tail(agg, center, residual, self.lin_ih, self.lin_hh, self.lin_self, self.out_proj,
                                          self.proj_drop.p, self.proj_drop.training)

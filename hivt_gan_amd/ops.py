@@ -114,7 +114,7 @@ class _SegAttn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, num_heads, dropout_p, seed, tag,
-                padded, interleaved=False):
+                padded, interleaved=False, row_order=None):
         _need_gpu(q, kv, rowptr)
         n, d_model = q.shape
         e = kv.shape[0]
@@ -122,6 +122,9 @@ class _SegAttn(torch.autograd.Function):
             raise ValueError(f"kv must be [E, 2*D] (K | V), got {tuple(kv.shape)} for D={d_model}")
         if rowptr.shape[0] != n + 1:
             raise ValueError("rowptr must have num_targets + 1 entries")
+        if row_order is not None and (row_order.dtype != torch.int32 or row_order.shape != (n,)
+                                      or not row_order.is_contiguous()):
+            raise ValueError("row_order must be a contiguous int32 permutation of the target rows")
         q = _rows(q)  # (may be a column block of a wider product: its row stride goes to the kernel)
         kv = _rows(kv)
         if kv_node is not None:
@@ -136,17 +139,18 @@ class _SegAttn(torch.autograd.Function):
                     "hivt_seg_attn_fwd", _p(q), _ld(q), _p(kv), _p(kv, fb), kv.stride(0) if e > 0 else 2 * d_model,
                   _p(kv_node), _p(kv_node, fb) if kv_node is not None else None,
                   kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                    _p(rowptr), n, e, d_model, num_heads, float(dropout_p), int(seed), _seed_ptr(dropout_p), _p(out),
+                    _p(rowptr), _p(row_order), n, e, d_model, num_heads, float(dropout_p), int(seed),
+                    _seed_ptr(dropout_p), _p(out),
                     _p(m), _p(den), ROWS_INTERLEAVED if interleaved else 0, _stream(q))
         ctx.save_for_backward(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den,
-                              DEVICE_SEED if dropout_p > 0.0 else None)
+                              DEVICE_SEED if dropout_p > 0.0 else None, row_order)
         ctx.cfg = (num_heads, float(dropout_p), int(seed), tag, bool(padded), bool(interleaved))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_out):
-        q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den, seed_dev = ctx.saved_tensors
+        q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, out, m, den, seed_dev, row_order = ctx.saved_tensors
         num_heads, dropout_p, seed, tag, padded, interleaved = ctx.cfg
         n, d_model = q.shape
         e = kv.shape[0]
@@ -168,7 +172,8 @@ class _SegAttn(torch.autograd.Function):
                     kv.stride(0) if e > 0 else 2 * d_model,
                     _p(kv_node), _p(kv_node, fb_kv) if kv_node is not None else None,
                     kv_node.stride(0) if kv_node is not None else 0, _p(src) if kv_node is not None else None,
-                    _p(rowptr), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed, _p(seed_dev),
+                    _p(rowptr), _p(row_order), _p(out), _p(m), _p(den), n, e, d_model, num_heads, dropout_p, seed,
+                    _p(seed_dev),
                     _p(dq), _ld(dq), _p(dkv), _p(dkv, fb), 2 * d_model, 1 if padded else 0, layout, _stream(q),
                     grad_bytes=2 if half else 4)
         dkv_node = None
@@ -177,7 +182,7 @@ class _SegAttn(torch.autograd.Function):
             dkv_node = torch.empty(ns, 2 * d_model, dtype=torch.float32, device=q.device)
             _lib.call("hivt_segment_sum_rows", _p(dkv), 2 * d_model, 2 * d_model, _p(rowptr_by_src), _p(perm_by_src),
                       ns, _p(dkv_node), 2 * d_model, _stream(q))
-        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None, None, None
+        return dq, dkv, dkv_node, None, None, None, None, None, None, None, None, None, None, None
 
 
 ROWS_INTERLEAVED = 1 << 16  # layout flag in the dtype argument of hivt_seg_attn_fwd / _bwd
@@ -194,7 +199,8 @@ def seg_attn_supported(d_model: int, num_heads: int) -> bool:
 def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads: int, dropout_p: float = 0.0,
              training: bool = False, kv_node: Optional[torch.Tensor] = None, src: Optional[torch.Tensor] = None,
              rowptr_by_src: Optional[torch.Tensor] = None, perm_by_src: Optional[torch.Tensor] = None,
-             tag: str = "", padded: bool = False, interleaved: bool = False) -> torch.Tensor:
+             tag: str = "", padded: bool = False, interleaved: bool = False,
+             row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Segment-softmax attention over CSR rows.
 
     ``q`` [N,D]; ``kv`` [E,2D] holds K | V per edge in CSR order; optional ``kv_node`` [Ns,2D] adds the
@@ -211,7 +217,7 @@ def seg_attn(q: torch.Tensor, kv: torch.Tensor, rowptr: torch.Tensor, num_heads:
     if interleaved and (kv_node is not None or padded or q.shape[0] == 0 or kv.shape[0] % q.shape[0] != 0):
         raise ValueError("interleaved rows: E must be a multiple of N, without node terms or padding")
     return _SegAttn.apply(q, kv, kv_node, rowptr, src, rowptr_by_src, perm_by_src, int(num_heads), p, seed, tag,
-                          padded, bool(interleaved))
+                          padded, bool(interleaved), row_order)
 
 
 # --------------------------------------------------------------------------------------------
@@ -781,10 +787,11 @@ class _EdgeAttention(torch.autograd.Function):
     bfloat16 (between two nodes autograd would widen it to the forward tensor's dtype)."""
 
     @staticmethod
-    def forward(ctx, q, x, w_a, b_a, w_b, b_b, rowptr, num_heads, dropout_p, seed, tag, padded):
+    def forward(ctx, q, x, w_a, b_a, w_b, b_b, rowptr, num_heads, dropout_p, seed, tag, padded, row_order=None):
         proj, attn = _StandInContext(), _StandInContext()
         kv = _PairLinear.forward(proj, x, w_a, b_a, w_b, b_b)
-        out = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, dropout_p, seed, tag, padded)
+        out = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, dropout_p, seed, tag, padded,
+                               False, row_order)
         ctx.save_for_backward(*proj.saved_tensors, *attn.saved_tensors)
         ctx.split = len(proj.saved_tensors)
         ctx.stages = (proj.cfg, proj.param_leaves, attn.cfg)
@@ -807,12 +814,12 @@ class _EdgeAttention(torch.autograd.Function):
         grads = _SegAttn.backward(attn, d_out)
         dq, dkv = grads[0], grads[1]
         dx, dw_a, db_a, dw_b, db_b = _PairLinear.backward(proj, dkv)[:5]
-        return dq, dx, dw_a, db_a, dw_b, db_b, None, None, None, None, None, None
+        return dq, dx, dw_a, db_a, dw_b, db_b, None, None, None, None, None, None, None
 
 
 def edge_attention(q: torch.Tensor, x: torch.Tensor, a: torch.nn.Linear, b: torch.nn.Linear, rowptr: torch.Tensor,
                    num_heads: int, dropout_p: float = 0.0, training: bool = False, tag: str = "",
-                   padded: bool = False) -> torch.Tensor:
+                   padded: bool = False, row_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``seg_attn(q, pair_linear(x, a, b), rowptr, ...)`` as one autograd node: ``x`` [E, K] are the edge rows in CSR
     order, ``a`` / ``b`` the key and value projections, ``q`` [N, D] the queries.  Results equal the two calls' bit
     for bit in fp32 mode; in "bf16" mode the projected rows' gradient is kept as bfloat16 (the gradient products
@@ -821,7 +828,7 @@ def edge_attention(q: torch.Tensor, x: torch.Tensor, a: torch.nn.Linear, b: torc
         raise ValueError(f"edge rows must be [E, K], got {tuple(x.shape)}")
     p = float(dropout_p) if training else 0.0
     return _EdgeAttention.apply(q, x, a.weight, a.bias, b.weight, b.bias, rowptr, int(num_heads), p,
-                                _fresh_seed() if p > 0.0 else 0, tag, bool(padded))
+                                _fresh_seed() if p > 0.0 else 0, tag, bool(padded), row_order)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -1770,7 +1777,7 @@ class _AttentionBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, center, res, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params):
-        num_heads, p_attn, seed_attn, p_out, seed_out, tag, padded, node_terms = cfg
+        num_heads, p_attn, seed_attn, p_out, seed_out, tag, padded, node_terms, row_order = cfg
         if node_terms:
             (w_q, b_q, w_kn, b_kn, w_vn, b_vn, w_hh, b_hh, w_self, b_self, w_k, b_k, w_v, b_v, w_ih, b_ih, w_out,
              b_out) = params
@@ -1801,7 +1808,8 @@ class _AttentionBlock(torch.autograd.Function):
             kv = _PairLinear.forward(proj, edge_rows, w_k, b_k, w_v, b_v, a[:, d:3 * d], src, rowptr_by_src, perm_by_src)
         else:
             kv = _PairLinear.forward(proj, edge_rows, w_k, b_k, w_v, b_v)
-        agg = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, p_attn, seed_attn, tag, padded)
+        agg = _SegAttn.forward(attn, q, kv, None, rowptr, None, None, None, num_heads, p_attn, seed_attn, tag, padded,
+                               False, row_order)
         ih = torch.empty(n, d, dtype=torch.float32, device=dev)
         upd = torch.empty(n, d, dtype=torch.float32, device=dev)
         y = torch.empty(n, d, dtype=torch.float32, device=dev)
@@ -1896,12 +1904,15 @@ def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: tor
                     lin_q, lin_k, lin_v, lin_ih, lin_hh, lin_self, out_proj, num_heads: int, p_attn: float, p_out: float,
                     training: bool, tag: str = "", padded: bool = False, lin_k_node=None, lin_v_node=None,
                     src: Optional[torch.Tensor] = None, rowptr_by_src: Optional[torch.Tensor] = None,
-                    perm_by_src: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    perm_by_src: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None
+                    ) -> torch.Tensor:
     """One edge-attention block -- query / key / value projections, segment-softmax attention over the CSR rows,
     gate, update, output projection, dropout and residual -- as one autograd node.  ``center`` [N, D]: the
     normalised target rows; ``edge_rows`` [E, K]: the per-edge embeddings in CSR order; ``residual`` [N, D].  With
     ``lin_k_node`` / ``lin_v_node`` (the interaction module) an edge's key | value also receive the node terms of its
-    source ``src[e]`` (int32, CSR order; the CSR over sources gives their gradient), and sources are the centre rows."""
+    source ``src[e]`` (int32, CSR order; the CSR over sources gives their gradient), and sources are the centre rows.
+    ``row_order`` (int32 [N], from ``csr_build(..., order=True)``): the order in which the attention launches start
+    their rows -- a schedule, the results do not depend on it."""
     pa = float(p_attn) if training else 0.0
     po = float(p_out) if training else 0.0
     node_terms = lin_k_node is not None
@@ -1913,7 +1924,7 @@ def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: tor
     params += [lin_hh.weight, lin_hh.bias, lin_self.weight, lin_self.bias, lin_k.weight, lin_k.bias, lin_v.weight,
                lin_v.bias, lin_ih.weight, lin_ih.bias, out_proj.weight, out_proj.bias]
     cfg = (int(num_heads), pa, _fresh_seed() if pa > 0.0 else 0, po, _fresh_seed() if po > 0.0 else 0, tag,
-           bool(padded), node_terms)
+           bool(padded), node_terms, row_order)
     return _AttentionBlock.apply(center, residual, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params)
 
 

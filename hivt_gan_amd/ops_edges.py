@@ -75,10 +75,11 @@ def edges_radius(edge_index: torch.Tensor, edge_attr: torch.Tensor, radius: Opti
     return src, dst, attr, count
 
 
-def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = None
-              ) -> Tuple[torch.Tensor, torch.Tensor]:
+def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = None, order: bool = False):
     """Stable grouping of edge positions by ``key``: returns (rowptr int32 [num_rows+1], perm int32 [E]).
-    ``count`` (device int32 scalar) marks the live prefix of a list padded to a fixed capacity."""
+    ``count`` (device int32 scalar) marks the live prefix of a list padded to a fixed capacity.  With ``order`` a
+    third result: the rows ranked by length, longest first (int32 [num_rows]; the schedule that ``seg_attn`` and
+    the attention blocks take as ``row_order``)."""
     _need_gpu(key)
     if key.dtype != torch.int32 or key.dim() != 1:
         raise ValueError("key must be an int32 vector")
@@ -87,10 +88,11 @@ def csr_build(key: torch.Tensor, num_rows: int, count: Optional[torch.Tensor] = 
     dev = key.device
     rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
+    ranked = torch.empty(num_rows, dtype=torch.int32, device=dev) if order else None
     ws = _workspace(_lib.query("hivt_csr_workspace_bytes", e, num_rows), dev)
-    _lib.call("hivt_csr_build", _p(key), e, _p(count), num_rows, _p(rowptr), _p(perm), _p(ws), ws.numel(),
+    _lib.call("hivt_csr_build", _p(key), e, _p(count), num_rows, _p(rowptr), _p(perm), _p(ranked), _p(ws), ws.numel(),
               _stream(key))
-    return rowptr, perm
+    return (rowptr, perm, ranked) if order else (rowptr, perm)
 
 
 def edges_all_pairs_csr(scene_range: torch.Tensor, padding_mask: torch.Tensor, positions: torch.Tensor, t0: int,
@@ -148,6 +150,7 @@ class EdgeSet:
     rowptr_by_src: Optional[torch.Tensor] = None
     perm_by_src: Optional[torch.Tensor] = None
     count: Optional[torch.Tensor] = None  # device int32: live edges when the lists are padded to a capacity
+    row_order: Optional[torch.Tensor] = None  # int32 [num_dst]: target rows, longest first (a launch schedule)
 
     @property
     def num_edges(self) -> int:
@@ -164,10 +167,11 @@ class EdgeSet:
 
 
 def make_edge_set(src: torch.Tensor, dst: torch.Tensor, attr: torch.Tensor, num_src: int, num_dst: int,
-                  count: Optional[torch.Tensor] = None) -> EdgeSet:
-    """Group an already filtered int32 COO list by target (``count``: live prefix of padded lists)."""
-    rowptr, perm = csr_build(dst, num_dst, count)
-    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm, count=count)
+                  count: Optional[torch.Tensor] = None, order: bool = False) -> EdgeSet:
+    """Group an already filtered int32 COO list by target (``count``: live prefix of padded lists; ``order``: also
+    rank the target rows by length, for sets whose row lengths are spread widely)."""
+    rowptr, perm, *ranked = csr_build(dst, num_dst, count, order)
+    return EdgeSet(num_src, num_dst, src, dst, attr, rowptr, perm, count=count, row_order=ranked[0] if order else None)
 
 
 # --------------------------------------------------------------------------------------------

@@ -108,9 +108,12 @@ size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows);
  * `count` (device int32, may be NULL) gives the number of meaningful entries when the list is
  * padded to a fixed capacity E: entries at or beyond *count are ignored, rowptr[num_rows] = *count
  * and perm[*count .. E) is left untouched.  This lets a captured HIP graph be replayed on batches
- * with different edge counts. */
+ * with different edge counts.
+ * `row_order` (int32 [num_rows], may be NULL) receives the rows ranked by length, longest first (classes of two
+ * lengths; the order inside a class is unspecified): a schedule for kernels that give every row a workgroup, see
+ * hivt_seg_attn_fwd.  It costs no launch: the ranking is part of the scan of the row lengths. */
 int hivt_csr_build(const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows, int32_t* rowptr,
-                   int32_t* perm, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
+                   int32_t* perm, int32_t* row_order, void* workspace, size_t workspace_bytes, hivt_stream_t stream);
 
 /* hivt_csr_build without a workspace and without any allocation: the scratch (row cursors and the
  * unordered placement) is a static device array inside the library, HIVT_CSR_STATIC_MAX_ROWS +
@@ -290,11 +293,14 @@ int hivt_edge_relpose_fwd(const float* attr, const float* rot, const float* angl
  * Saves the per-(row,head) max `m_out` and denominator `den_out` (float [N,H]) for backward.
  * Dropout (p > 0) uses a counter-based generator keyed on (seed + *seed_ptr, CSR position, head);
  * seed_ptr (device uint64, may be NULL) lets a captured graph draw fresh masks on every replay.
- * E is the number of k / v rows (a fixed capacity is fine: rows beyond rowptr[N] are never read). */
+ * E is the number of k / v rows (a fixed capacity is fine: rows beyond rowptr[N] are never read).
+ * `row_order` (int32 [N], a permutation of the rows, may be NULL) is a schedule, not data: the g-th workgroup slot of
+ * the launch serves row row_order[g], so with hivt_csr_build's ranking the long rows start first and the launch does
+ * not end on a few of them.  Results do not depend on it.  Launch shapes that share a wave among rows ignore it. */
 int hivt_seg_attn_fwd(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                       const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                      int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                      const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                      const int32_t* row_order, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                      uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
                       hivt_stream_t stream);
 
 /* Backward of hivt_seg_attn_fwd: dq float [N,D] with element stride dq_stride; dk / dv float rows in CSR order with element
@@ -304,9 +310,9 @@ int hivt_seg_attn_fwd(const float* q, int64_t q_stride, const float* k, const fl
  * [rowptr[N], E) of dk / dv (padding of a fixed-capacity list) are set to zero. */
 int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                       const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
-                      const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                      int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed, const uint64_t* seed_ptr,
-                      float* dq, int64_t dq_stride, float* dk, float* dv, int64_t dkv_stride, int32_t zero_tail,
+                      const int32_t* rowptr, const int32_t* row_order, const float* out, const float* m,
+                      const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
+                      const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv, int64_t dkv_stride, int32_t zero_tail,
                       int dtype, hivt_stream_t stream);
 
 /* hivt_seg_attn_fwd / _bwd with in-application timing: identical computation; additionally the
@@ -315,14 +321,14 @@ int hivt_seg_attn_bwd(const float* d_out, const float* q, int64_t q_stride, cons
  * dispatch gaps that events recorded around a launch include.  No counterpart in the reference. */
 int hivt_seg_attn_fwd_timed(const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride, const float* k_node,
                             const float* v_node, int64_t node_stride, const int32_t* src, const int32_t* rowptr,
-                            int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                            const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
+                            const int32_t* row_order, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                            uint64_t seed, const uint64_t* seed_ptr, float* out, float* m_out, float* den_out, int dtype,
                             hivt_stream_t stream, void* start_event, void* stop_event);
 int hivt_seg_attn_bwd_timed(const float* d_out, const float* q, int64_t q_stride, const float* k, const float* v, int64_t kv_stride,
                             const float* k_node, const float* v_node, int64_t node_stride, const int32_t* src,
-                            const int32_t* rowptr, const float* out, const float* m, const float* den, int32_t N,
-                            int64_t E, int32_t D, int32_t H, float dropout_p, uint64_t seed,
-                            const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
+                            const int32_t* rowptr, const int32_t* row_order, const float* out, const float* m,
+                            const float* den, int32_t N, int64_t E, int32_t D, int32_t H, float dropout_p,
+                            uint64_t seed, const uint64_t* seed_ptr, float* dq, int64_t dq_stride, float* dk, float* dv,
                             int64_t dkv_stride, int32_t zero_tail, int dtype, hivt_stream_t stream, void* start_event,
                             void* stop_event);
 

@@ -29,7 +29,7 @@ def _both(key: torch.Tensor, num_rows: int, count=None):
         else:
             nbytes = lib.hivt_csr_workspace_bytes(e, num_rows)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = lib.hivt_csr_build(key.data_ptr(), e, cptr, num_rows, rowptr.data_ptr(), perm.data_ptr(),
+            rc = lib.hivt_csr_build(key.data_ptr(), e, cptr, num_rows, rowptr.data_ptr(), perm.data_ptr(), None,
                                     ws.data_ptr(), nbytes, stream)
         assert rc == 0, lib.hivt_last_error().decode()
         outs.append((rowptr, perm))

@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--shuffled", action="store_true", help="the same row lengths in a random order")
     ap.add_argument("--sorted", action="store_true",
                     help="rows in descending order of length (same multiset of lengths): what the ORDER of the rows costs")
+    ap.add_argument("--ranked", action="store_true",
+                    help="hand the launches the CSR build's ranking of the rows by length (sets that carry one)")
     ap.add_argument("--half-grads", action="store_true",
                     help="backward writes dK | dV as bfloat16 rows (sets without node terms only)")
     args = ap.parse_args()
@@ -92,20 +94,26 @@ def main():
         fb = 4 * D
         gfb = 2 * D if half else 4 * D      # byte offset of dV inside a dK | dV row
         gflag = ops.DKV_BF16 if half else 0
+        order_ptr = None
+        if args.ranked:
+            ranked = es.row_order
+            if ranked is None:  # a set built without the ranking: the same order from the host, to price it
+                ranked = torch.argsort(es.rowptr[1:] - es.rowptr[:-1], descending=True, stable=True).to(torch.int32)
+            order_ptr = ranked.data_ptr()
         results = {"fwd": {}, "bwd": {}}
 
         def fwd(hint_bits, ev0, ev1, kv):
             _lib.call("hivt_seg_attn_fwd_timed", q.data_ptr(), D, kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
                       kv_node.data_ptr() if node_terms else None, kv_node.data_ptr() + fb if node_terms else None,
-                      2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(), n, e, D,
-                      H, 0.1, 1234, None, out.data_ptr(), m.data_ptr(), den.data_ptr(), hint_bits, stream.cuda_stream,
+                      2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(), order_ptr,
+                      n, e, D, H, 0.1, 1234, None, out.data_ptr(), m.data_ptr(), den.data_ptr(), hint_bits, stream.cuda_stream,
                       int(ev0.cuda_event), int(ev1.cuda_event))
 
         def bwd(hint_bits, ev0, ev1, kv):
             _lib.call("hivt_seg_attn_bwd_timed", d_out.data_ptr(), q.data_ptr(), D, kv.data_ptr(), kv.data_ptr() + fb, 2 * D,
                       kv_node.data_ptr() if node_terms else None, kv_node.data_ptr() + fb if node_terms else None,
                       2 * D if node_terms else 0, src.data_ptr() if node_terms else None, es.rowptr.data_ptr(),
-                      out.data_ptr(), m.data_ptr(), den.data_ptr(), n, e, D, H, 0.1, 1234, None, dq.data_ptr(), D,
+                      order_ptr, out.data_ptr(), m.data_ptr(), den.data_ptr(), n, e, D, H, 0.1, 1234, None, dq.data_ptr(), D,
                       dkv.data_ptr(), dkv.data_ptr() + gfb, 2 * D, 0, hint_bits | gflag, stream.cuda_stream,
                       int(ev0.cuda_event), int(ev1.cuda_event))
 
