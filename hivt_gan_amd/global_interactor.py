@@ -49,19 +49,20 @@ class GlobalInteractorLayer(nn.Module):
                 (self.lin_k_edge, self.lin_v_edge)]
 
     def forward(self, x: torch.Tensor, edge_index: Optional[torch.Tensor], edge_attr: torch.Tensor, size=None,
-                edges: Optional[EdgeSet] = None) -> torch.Tensor:
+                edges: Optional[EdgeSet] = None, edge_grad_sink=None) -> torch.Tensor:
         """With ``edges`` given, ``edge_attr`` [E, D] is already in its CSR order; otherwise
-        ``edge_index`` / ``edge_attr`` are the reference's COO list and per-edge embeddings."""
+        ``edge_index`` / ``edge_attr`` are the reference's COO list and per-edge embeddings.  ``edge_grad_sink``:
+        ``edge_attr`` came from ``ops.share_edge_rows`` (several layers read it)."""
         if edges is None:
             edges = _edge_set_from_coo(edge_index, edge_attr.new_zeros(edge_attr.shape[0], 2), x.shape[0], x.shape[0])
             edges.src = edges.coo_src.index_select(0, edges.perm.long())
             edge_attr = edge_attr.index_select(0, edges.perm.long())
         normed, x = ops.layer_norm_residual(x, self.norm1)
-        x = self._mha_block(normed, edges, edge_attr, residual=x)
+        x = self._mha_block(normed, edges, edge_attr, residual=x, edge_grad_sink=edge_grad_sink)
         return _pre_norm_ffn(x, self.norm2, self.mlp)
 
     def _mha_block(self, x: torch.Tensor, edges: EdgeSet, edge_attr: torch.Tensor,
-                   residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   residual: Optional[torch.Tensor] = None, edge_grad_sink=None) -> torch.Tensor:
         edges.group_by_source()
         if ops.attention_block_supported(x, edge_attr, residual) and edges.src.dtype == torch.int32:
             return ops.attention_block(x, residual, edge_attr, edges.rowptr, self.lin_q_node, self.lin_k_edge,
@@ -69,7 +70,8 @@ class GlobalInteractorLayer(nn.Module):
                                        self.num_heads, self.attn_drop.p, self.proj_drop.p, self.training,
                                        tag=type(self).__name__, padded=edges.count is not None,
                                        lin_k_node=self.lin_k_node, lin_v_node=self.lin_v_node, src=edges.src,
-                                       rowptr_by_src=edges.rowptr_by_src, perm_by_src=edges.perm_by_src)
+                                       rowptr_by_src=edges.rowptr_by_src, perm_by_src=edges.perm_by_src,
+                                       edge_grad_sink=edge_grad_sink)
         q = _linear(x, self.lin_q_node)
         kv_node = _fused_linear(x, self.lin_k_node, self.lin_v_node)
         if edge_attr.is_cuda and edge_attr.dtype == torch.float32 and edges.src.dtype == torch.int32:
@@ -132,8 +134,13 @@ class GlobalInteractor(nn.Module):
             rel_embed = self.rel_embed.forward_packed(feat)
         edges.src = src_csr
         x = local_embed
+        sink = None
+        if (len(self.global_interactor_layers) > 1 and rel_embed.requires_grad and torch.is_grad_enabled()
+                and ops.attention_block_supported(x, rel_embed, x) and src_csr.dtype == torch.int32):
+            # every layer reads the embeddings: their gradient is summed inside the layers' own products
+            rel_embed, sink = ops.share_edge_rows(rel_embed)
         for layer in self.global_interactor_layers:
-            x = layer(x, None, rel_embed, edges=edges)
+            x = layer(x, None, rel_embed, edges=edges, edge_grad_sink=sink)
         x = ops.layer_norm(x, self.norm)
         if x.is_cuda and x.dtype == torch.float32:
             x = ops.fused_linear(x, self.multihead_proj.weight, self.multihead_proj.bias)

@@ -733,12 +733,16 @@ class _PairLinear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(m, k, dtype=torch.float32, device=dev)
+            # (a caller that runs this node itself may name rows to add: the input's gradient by its other routes)
+            add = getattr(ctx, "dx_add", None)
+            if add is not None and (add.shape != (m, k) or add.dtype != torch.float32 or add.stride(1) != 1):
+                raise RuntimeError("the rows added to the input gradient must be float32 [rows, width]")
             if half:
-                _lib.call("hivt_linear_bwd_data_half", _p(dy2), n, _p(w), w.stride(0), m, n, k, None, 0, 1.0, None, 0,
-                          _p(dx), k, HALF_DY, s)
+                _lib.call("hivt_linear_bwd_data_half", _p(dy2), n, _p(w), w.stride(0), m, n, k, None, 0, 1.0, _p(add),
+                          _ld(add) if add is not None else 0, _p(dx), k, HALF_DY, s)
             else:
-                _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0, None,
-                          0, _p(dx), k, s)
+                _lib.call("hivt_linear_bwd_data", _p(dy2), dy2.stride(0), _p(w), w.stride(0), m, n, k, None, 0, 1.0,
+                          _p(add), _ld(add) if add is not None else 0, _p(dx), k, s)
             dx = dx.view(*lead, k)
         dw, db = _weight_grad(dy2, dy2.stride(0), x2, x2.stride(0), m, n, k, dev, leaves=ctx.param_leaves)
         d_table = None
@@ -1761,6 +1765,45 @@ def gated_update_tail(agg: torch.Tensor, center: torch.Tensor, residual: torch.T
 # --------------------------------------------------------------------------------------------
 # A whole edge-attention block as ONE autograd node
 # --------------------------------------------------------------------------------------------
+class GradSink:
+    """Running sum of the gradients that several attention blocks produce for ONE tensor of edge rows they all
+    read (the interaction module's relative-pose embeddings feed every one of its layers).  Each block's data-gradient
+    product adds the sum so far in its store epilogue and leaves its result here instead of returning it; the node
+    that handed the rows out (``share_edge_rows``) returns the total.  Autograd would sum the blocks' gradients with
+    one elementwise launch per extra reader, each a pass over three tensors of the edge rows' size."""
+
+    def __init__(self) -> None:
+        self.total: Optional[torch.Tensor] = None
+
+    def take(self) -> Optional[torch.Tensor]:
+        total, self.total = self.total, None
+        return total
+
+
+class _SharedEdgeRows(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, rows, sink):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return rows.view_as(rows)
+
+    @staticmethod
+    def backward(ctx, grad):
+        # runs after every reader of this pass: the blocks' share is in the sink, other readers' arrives here
+        total = ctx.sink.take()
+        if grad is not None:
+            total = grad if total is None else total + grad
+        return total, None
+
+
+def share_edge_rows(rows: torch.Tensor):
+    """``(rows, sink)`` for edge rows that several ``attention_block`` calls read: pass ``sink`` to each of them as
+    ``edge_grad_sink`` and the rows' gradient is summed inside the blocks' own products (see ``GradSink``)."""
+    sink = GradSink()
+    return _SharedEdgeRows.apply(rows, sink), sink
+
+
 class _AttentionBlock(torch.autograd.Function):
     """``res + drop(out_proj(agg + sigmoid(lin_ih(agg) + lin_hh(c)) * (lin_self(c) - agg)))`` with
     ``agg = seg_attn(lin_q(c), [lin_k | lin_v](edge rows) [+ [lin_k_node | lin_v_node](c)[src]], rowptr)``
@@ -1777,7 +1820,7 @@ class _AttentionBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, center, res, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params):
-        num_heads, p_attn, seed_attn, p_out, seed_out, tag, padded, node_terms, row_order = cfg
+        num_heads, p_attn, seed_attn, p_out, seed_out, tag, padded, node_terms, row_order, ctx.edge_sink = cfg
         if node_terms:
             (w_q, b_q, w_kn, b_kn, w_vn, b_vn, w_hh, b_hh, w_self, b_self, w_k, b_k, w_v, b_v, w_ih, b_ih, w_out,
              b_out) = params
@@ -1878,7 +1921,13 @@ class _AttentionBlock(torch.autograd.Function):
         dkv = _SegAttn.backward(attn, d_agg)[1]
         if node_terms:
             proj.d_table_out = da[:, d:3 * d]
+        sink = ctx.edge_sink if need[2] else None
+        if sink is not None:
+            proj.dx_add = sink.total
         d_edge, dw_k, db_k, dw_v, db_v = _PairLinear.backward(proj, dkv)[:5]
+        if sink is not None:
+            # (the sum so far went into this product's epilogue; the node that shared the rows returns the total)
+            sink.total, d_edge = d_edge.reshape(x2.shape), None
 
         dwc, dbc = wgrad(da, c2, nc)
         d_center = None
@@ -1904,15 +1953,16 @@ def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: tor
                     lin_q, lin_k, lin_v, lin_ih, lin_hh, lin_self, out_proj, num_heads: int, p_attn: float, p_out: float,
                     training: bool, tag: str = "", padded: bool = False, lin_k_node=None, lin_v_node=None,
                     src: Optional[torch.Tensor] = None, rowptr_by_src: Optional[torch.Tensor] = None,
-                    perm_by_src: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None
-                    ) -> torch.Tensor:
+                    perm_by_src: Optional[torch.Tensor] = None, row_order: Optional[torch.Tensor] = None,
+                    edge_grad_sink: Optional[GradSink] = None) -> torch.Tensor:
     """One edge-attention block -- query / key / value projections, segment-softmax attention over the CSR rows,
     gate, update, output projection, dropout and residual -- as one autograd node.  ``center`` [N, D]: the
     normalised target rows; ``edge_rows`` [E, K]: the per-edge embeddings in CSR order; ``residual`` [N, D].  With
     ``lin_k_node`` / ``lin_v_node`` (the interaction module) an edge's key | value also receive the node terms of its
     source ``src[e]`` (int32, CSR order; the CSR over sources gives their gradient), and sources are the centre rows.
     ``row_order`` (int32 [N], from ``csr_build(..., order=True)``): the order in which the attention launches start
-    their rows -- a schedule, the results do not depend on it."""
+    their rows -- a schedule, the results do not depend on it.  ``edge_grad_sink``: ``edge_rows`` came from
+    ``share_edge_rows`` and their gradient is summed across the blocks that read them."""
     pa = float(p_attn) if training else 0.0
     po = float(p_out) if training else 0.0
     node_terms = lin_k_node is not None
@@ -1924,7 +1974,7 @@ def attention_block(center: torch.Tensor, residual: torch.Tensor, edge_rows: tor
     params += [lin_hh.weight, lin_hh.bias, lin_self.weight, lin_self.bias, lin_k.weight, lin_k.bias, lin_v.weight,
                lin_v.bias, lin_ih.weight, lin_ih.bias, out_proj.weight, out_proj.bias]
     cfg = (int(num_heads), pa, _fresh_seed() if pa > 0.0 else 0, po, _fresh_seed() if po > 0.0 else 0, tag,
-           bool(padded), node_terms, row_order)
+           bool(padded), node_terms, row_order, edge_grad_sink)
     return _AttentionBlock.apply(center, residual, edge_rows, rowptr, src, rowptr_by_src, perm_by_src, cfg, *params)
 
 

@@ -126,3 +126,43 @@ def test_segment_sum_of_bfloat16_rows_equals_the_sum_of_the_widened_rows():
     assert torch.equal(out_h, out_f)
     ref = torch.zeros(n, width, dtype=torch.float64, device=dev).index_add_(0, src.to(dev), wide.double())
     assert float((out_f.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_shared_edge_rows_sum_their_gradient_inside_the_blocks(precision):
+    """Three blocks read the same edge rows: with a sink the rows' gradient is the sum that autograd would form (the
+    same products, the running sum added in the store epilogue), and rows that also have another reader get that
+    reader's gradient added by the sharing node."""
+    from hivt_gan_amd import ops
+    dev = torch.device("cuda", 0)
+    d, heads, n, e = 128, 8, 500, 6000
+    gen = torch.Generator().manual_seed(13)
+    blocks = [_modules(d, False, dev) for _ in range(3)]
+    rowptr = _csr(n, e, dev, gen)
+    center0 = torch.randn(n, d, generator=gen).to(dev)
+    edge0 = torch.randn(e, d, generator=gen).to(dev)
+    weight = torch.randn(n, d, generator=gen).to(dev)
+    side = torch.randn(e, d, generator=gen).to(dev)
+    prev = ops.set_matmul_precision(precision)
+    try:
+        def run(shared):
+            for lin in blocks:
+                for m in lin.values():
+                    for p in m.parameters():
+                        p.grad = None
+            x = edge0.clone().requires_grad_(True)
+            c = center0.clone().requires_grad_(True)
+            rows, sink = ops.share_edge_rows(x) if shared else (x, None)
+            h = c
+            for lin in blocks:
+                h = ops.attention_block(h, h, rows, rowptr, lin["q"], lin["k"], lin["v"], lin["ih"], lin["hh"],
+                                        lin["self"], lin["out"], heads, 0.0, 0.0, True, edge_grad_sink=sink)
+            ((h * weight).sum() + (rows * side).sum()).backward()
+            assert sink is None or sink.total is None  # taken by the sharing node
+            return x.grad, c.grad, blocks[0]["k"].weight.grad.clone()
+
+        plain, shared = run(False), run(True)
+    finally:
+        ops.set_matmul_precision(prev)
+    for a, b in zip(plain, shared):
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
