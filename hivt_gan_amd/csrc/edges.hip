@@ -163,16 +163,29 @@ __global__ __launch_bounds__(1024) void scan_rank_single_block_kernel(const int3
   }
   if (tid == 1023 && total_out != nullptr) *total_out = part[1023];
   __syncthreads();
-  // exclusive scan of the class counts (part is free again), then every row takes the next slot of its class
-  if (tid < kLengthClasses) part[tid] = cls[tid];
-  __syncthreads();
-  for (int o = 1; o < kLengthClasses; o <<= 1) {
-    int v = (tid < kLengthClasses && tid >= o) ? part[tid - o] : 0;
-    __syncthreads();
-    if (tid < kLengthClasses) part[tid] += v;
-    __syncthreads();
+  // exclusive scan of the class counts by one wave (eight classes per lane), then every row takes the next slot of
+  // its class
+  if (tid < kWave) {
+    constexpr int PER = kLengthClasses / kWave;
+    int c[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      c[j] = cls[tid * PER + j];
+      sum += c[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int v = __shfl_up(incl, o, kWave);
+      if (tid >= o) incl += v;
+    }
+    int first = incl - sum;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      cls[tid * PER + j] = first;  // first slot of the class
+      first += c[j];
+    }
   }
-  if (tid < kLengthClasses) cls[tid] = part[tid] - cls[tid];  // first slot of the class
   __syncthreads();
   for (int64_t i = lo; i < hi; ++i) order[atomicAdd(&cls[class_of(in[i])], 1)] = (int32_t)i;
 }
@@ -366,15 +379,16 @@ __global__ void csr_hist_kernel(const int32_t* __restrict__ key, int64_t E, cons
   if (i < live_entries(E, count)) atomicAdd(&deg[key[i]], 1);
 }
 
-// Unordered placement: slot = rowptr[key] + arrival ticket.  The order inside a row is fixed
-// afterwards by csr_row_sort_kernel, so the result does not depend on atomic arrival order.
+// Unordered placement: slot = rowptr[key] + arrival ticket, the tickets counted DOWN from the row's length that the
+// histogram left in `cursor` (no second clearing of the cursors between the two passes).  The order inside a row is
+// fixed afterwards by csr_row_sort_kernel, so the result does not depend on atomic arrival order.
 __global__ void csr_place_kernel(const int32_t* __restrict__ key, int64_t E, const int32_t* __restrict__ count,
                                  const int32_t* __restrict__ rowptr, int32_t* __restrict__ cursor,
                                  int32_t* __restrict__ tmp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < live_entries(E, count)) {
     const int32_t k = key[i];
-    const int32_t slot = rowptr[k] + atomicAdd(&cursor[k], 1);
+    const int32_t slot = rowptr[k] + atomicSub(&cursor[k], 1) - 1;
     tmp[slot] = (int32_t)i;
   }
 }
@@ -576,7 +590,7 @@ extern "C" size_t hivt_csr_workspace_bytes(int64_t E, int32_t num_rows) {
 static int csr_build_launch(const char* what, const int32_t* key, int64_t E, const int32_t* count, int32_t num_rows,
                             int32_t* rowptr, int32_t* perm, int32_t* cursor, int32_t* tmp, hipStream_t stream,
                             int32_t* row_order = nullptr) {
-  // degree histogram goes into `cursor`, the scan of it into rowptr, then cursor is reused as tickets
+  // degree histogram goes into `cursor`, the scan of it into rowptr, then the counts are the placement's tickets
   zero_words(cursor, num_rows > 0 ? num_rows : 1, stream);
   HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
@@ -592,8 +606,6 @@ static int csr_build_launch(const char* what, const int32_t* key, int64_t E, con
                        rowptr + num_rows);
   HIVT_CHECK_LAUNCH(what);
   if (E > 0) {
-    zero_words(cursor, num_rows, stream);
-    HIVT_CHECK_LAUNCH(what);
     hipLaunchKernelGGL(csr_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, stream, key, E, count,
                        rowptr, cursor, tmp);
     HIVT_CHECK_LAUNCH(what);
