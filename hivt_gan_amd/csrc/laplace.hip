@@ -257,15 +257,21 @@ __global__ void guard_init_kernel(const uint8_t* __restrict__ extra, int32_t* __
   if (threadIdx.x == 0 && blockIdx.x == 0) flag[0] = (extra != nullptr && extra[0] != 0) ? 1 : 0;
 }
 
-// FINITE = false: looks for NaN; true: for NaN or infinity.  A block that finds one ORs 1 into the flag
-// (an idempotent integer atomic: the result does not depend on arrival order).
-template <bool FINITE>
-__global__ __launch_bounds__(256) void guard_scan_kernel(const float* __restrict__ x, int64_t n, int32_t* __restrict__ flag) {
+// Both scans of a step's guards in one launch: the first `nan_blocks` workgroups look for NaN in x_nan, the others
+// for NaN or infinity in x_fin.  A wave that finds one ORs 1 into the flag (an idempotent integer atomic: the
+// result does not depend on arrival order).
+__global__ __launch_bounds__(256) void guard_scan_kernel(const float* __restrict__ x_nan, int64_t n_nan, int nan_blocks,
+                                                         const float* __restrict__ x_fin, int64_t n_fin,
+                                                         int32_t* __restrict__ flag) {
+  const bool finite = (int)blockIdx.x >= nan_blocks;
+  const float* __restrict__ x = finite ? x_fin : x_nan;
+  const int64_t n = finite ? n_fin : n_nan;
+  const int64_t block = finite ? (int)blockIdx.x - nan_blocks : (int)blockIdx.x;
+  const int64_t stride = (int64_t)(finite ? (int)gridDim.x - nan_blocks : nan_blocks) * blockDim.x;
   bool bad = false;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (int64_t i = block * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = x[i];
-    bad |= FINITE ? !(fabsf(v) <= 3.402823466e38f) : (v != v);
+    bad |= finite ? !(fabsf(v) <= 3.402823466e38f) : (v != v);
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
@@ -281,14 +287,11 @@ extern "C" int hivt_step_guards(const float* nan_check, int64_t n_nan, const flo
   HIVT_REQUIRE((n_nan == 0 || nan_check) && (n_finite == 0 || finite_check), HIVT_ERR_ARG, "%s: null pointer", what);
   hipLaunchKernelGGL(guard_init_kernel, dim3(1), dim3(64), 0, stream, extra, flag);
   HIVT_CHECK_LAUNCH(what);
-  auto blocks = [](int64_t n) { int64_t b = (n + 1023) / 1024; return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); };
-  if (n_nan > 0) {
-    hipLaunchKernelGGL((guard_scan_kernel<false>), dim3(blocks(n_nan)), dim3(256), 0, stream, nan_check, n_nan, flag);
-    HIVT_CHECK_LAUNCH(what);
-  }
-  if (n_finite > 0) {
-    hipLaunchKernelGGL((guard_scan_kernel<true>), dim3(blocks(n_finite)), dim3(256), 0, stream, finite_check, n_finite,
-                       flag);
+  auto blocks = [](int64_t n) { int64_t b = (n + 1023) / 1024; return (int)(b > 1024 ? 1024 : b); };  // 0 for n = 0
+  const int nan_blocks = blocks(n_nan), fin_blocks = blocks(n_finite);
+  if (nan_blocks + fin_blocks > 0) {
+    hipLaunchKernelGGL(guard_scan_kernel, dim3((unsigned)(nan_blocks + fin_blocks)), dim3(256), 0, stream, nan_check, n_nan,
+                       nan_blocks, finite_check, n_finite, flag);
     HIVT_CHECK_LAUNCH(what);
   }
   return HIVT_OK;
