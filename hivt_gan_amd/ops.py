@@ -1770,13 +1770,27 @@ class GradSink:
     read (the interaction module's relative-pose embeddings feed every one of its layers).  Each block's data-gradient
     product adds the sum so far in its store epilogue and leaves its result here instead of returning it; the node
     that handed the rows out (``share_edge_rows``) returns the total.  Autograd would sum the blocks' gradients with
-    one elementwise launch per extra reader, each a pass over three tensors of the edge rows' size."""
+    one elementwise launch per extra reader, each a pass over three tensors of the edge rows' size.
+    A sum belongs to the backward pass that formed it (autograd's graph-task id): a pass that never reaches the
+    sharing node -- one that asks for other tensors' gradients only -- leaves a sum behind that no later pass
+    picks up."""
 
     def __init__(self) -> None:
-        self.total: Optional[torch.Tensor] = None
+        self._total: Optional[torch.Tensor] = None
+        self._task = -1
+
+    @property
+    def total(self) -> Optional[torch.Tensor]:
+        """The sum that the current backward pass has formed so far (None: nothing yet)."""
+        return self._total if self._task == torch._C._current_graph_task_id() else None
+
+    @total.setter
+    def total(self, value: Optional[torch.Tensor]) -> None:
+        self._total, self._task = value, torch._C._current_graph_task_id()
 
     def take(self) -> Optional[torch.Tensor]:
-        total, self.total = self.total, None
+        total = self.total
+        self._total, self._task = None, -1
         return total
 
 
