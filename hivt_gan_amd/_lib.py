@@ -86,6 +86,7 @@ SIGNATURES = {
                                          _P, _P, _P]),
     "hivt_embed2_fwd": (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P]),
     "hivt_embed2_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "hivt_embed2_bwd_partial_rows": (c_size_t, [c_int64, c_int32, c_int32]),
     "hivt_embed2_bwd": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_int64, c_int32, _P, _P, _P,
                                 c_size_t, _P]),
     "hivt_critic_saved_floats": (c_size_t, [c_int64, c_int32, _P, c_int32]),

@@ -245,10 +245,10 @@ extern "C" int hivt_embed2_bwd(const float* dh, const float* f, int64_t f_ld, in
   const char* what = "hivt_embed2_bwd";
   int rc = check(what, M, D, branches, f_ld, f);
   if (rc != HIVT_OK) return rc;
-  HIVT_REQUIRE(dparams != nullptr, HIVT_ERR_ARG, "%s: dparams is null", what);
   hipStream_t s = (hipStream_t)stream;
   const int cols = branches * 5 * D;
   if (M == 0) {
+    HIVT_REQUIRE(dparams != nullptr, HIVT_ERR_ARG, "%s: dparams is null (no rows: nothing to leave as partial sums)", what);
     zero_words(dparams, cols, s);
     HIVT_CHECK_LAUNCH(what);
     return HIVT_OK;
@@ -274,7 +274,13 @@ extern "C" int hivt_embed2_bwd(const float* dh, const float* f, int64_t f_ld, in
   else
     hipLaunchKernelGGL((embed2_bwd_kernel<64>), dim3(grid), dim3(kThreads), 0, s, a);
   HIVT_CHECK_LAUNCH(what);
+  if (dparams == nullptr) return HIVT_OK;  // the caller sums workspace[hivt_embed2_bwd_partial_rows][branches * 5 D]
   reduce_partials(a.partial, grid, cols, dparams, s);
   HIVT_CHECK_LAUNCH(what);
   return HIVT_OK;
+}
+
+extern "C" size_t hivt_embed2_bwd_partial_rows(int64_t M, int32_t D, int32_t branches) {
+  if ((D != 64 && D != 128) || M <= 0) return 0;
+  return (size_t)grid_for(M * branches, kWave / (D / 4));
 }

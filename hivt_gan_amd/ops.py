@@ -1102,6 +1102,7 @@ class _Embed2(torch.autograd.Function):
                   _ptr_array(betas), float(eps), m, d, _p(h), _stream(f))
         ctx.save_for_backward(f2, *ps)
         ctx.cfg = (branches, d, float(eps), tuple(lead), tuple(f.shape))
+        ctx.param_leaves = _all_leaves(*params)
         return h.view(*lead, branches * d)
 
     @staticmethod
@@ -1117,14 +1118,26 @@ class _Embed2(torch.autograd.Function):
             dh2 = dh2.contiguous()
         dparams = torch.empty(branches, 5 * d, dtype=torch.float32, device=dev)
         df = torch.empty(m, 2 * branches, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        ws_buf = _workspace(_lib.query("hivt_embed2_bwd_workspace_bytes", m, d, branches), dev)
-        _lib.call("hivt_embed2_bwd", _p(dh2), _p(f2), f2.stride(0), branches, _ptr_array(ws), _ptr_array(bs),
-                  _ptr_array(gs), _ptr_array(betas), eps, m, d, _p(dparams), _p(df), _p(ws_buf), ws_buf.numel(),
-                  _stream(f2))
+        nbytes = _lib.query("hivt_embed2_bwd_workspace_bytes", m, d, branches)
         grads = []
         for b in range(branches):
             row = dparams[b]
             grads += [row[:2 * d].view(d, 2), row[2 * d:3 * d], row[3 * d:4 * d], row[4 * d:5 * d]]
+        if m > 0 and _may_defer(ctx.param_leaves):
+            # the workgroups' partial sums wait for the one grouped reduction at the end of the backward pass
+            rows = _lib.query("hivt_embed2_bwd_partial_rows", m, d, branches)
+            part = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            _lib.call("hivt_embed2_bwd", _p(dh2), _p(f2), f2.stride(0), branches, _ptr_array(ws), _ptr_array(bs),
+                      _ptr_array(gs), _ptr_array(betas), eps, m, d, None, _p(df), _p(part), nbytes, _stream(f2))
+            _schedule_flush()
+            cols = branches * 5 * d
+            _deferred_rows.append(([part.data_ptr(), rows, cols, cols, dparams.data_ptr(), cols, 0, 0], dev, part,
+                                   (tuple(g.data_ptr() for g in grads), ctx.param_leaves)))
+        else:
+            ws_buf = _workspace(nbytes, dev)
+            _lib.call("hivt_embed2_bwd", _p(dh2), _p(f2), f2.stride(0), branches, _ptr_array(ws), _ptr_array(bs),
+                      _ptr_array(gs), _ptr_array(betas), eps, m, d, _p(dparams), _p(df), _p(ws_buf), ws_buf.numel(),
+                      _stream(f2))
         if df is not None:
             if f_shape[-1] != 2 * branches:  # the input row was wider than the columns the branches read
                 full = torch.zeros(m, f_shape[-1], dtype=torch.float32, device=dev)

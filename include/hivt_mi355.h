@@ -600,7 +600,11 @@ size_t hivt_embed2_bwd_workspace_bytes(int64_t M, int32_t D, int32_t branches);
 
 /* Gradients of the above from dh float [M, branches*D]; the pre-norm values are recomputed from f.
  * dparams float [branches][5*D] receives, per branch: dW (D x 2, row-major) | dbias | dgamma | dbeta.
+ * With dparams NULL (M > 0) the workgroups' partial sums stay in workspace as
+ * [hivt_embed2_bwd_partial_rows(M, D, branches)][branches*5*D] for the caller's own reduction (one
+ * hivt_reduce_rows_group over all such buffers of a backward pass gives the same sums bit for bit).
  * df (optional, float [M, 2*branches]) receives the input gradient. */
+size_t hivt_embed2_bwd_partial_rows(int64_t M, int32_t D, int32_t branches);
 int hivt_embed2_bwd(const float* dh, const float* f, int64_t f_ld, int32_t branches, const float* const* w,
                     const float* const* bias, const float* const* gamma, const float* const* beta, float eps,
                     int64_t M, int32_t D, float* dparams, float* df, void* workspace, size_t workspace_bytes,
